@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the MI355X rasterizer on BASELINE.json's configs.
+
+One step = one FRAME of the hot path for a model already resident in HBM (SURVEY.md
+section 8d): initialise the framebuffers (z = 1e6, colour = normal = 0), project all
+triangles, rasterize — `AdvancedPixelBufferFiller.render_model` on cleared buffers.
+Default workload: T-Rex.obj at 1024x1024, fov 45 (configs[1], the README benchmark).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is sharded into
+row strips, each rank rasterizes its strip and the strips are all-gathered with RCCL —
+one frame is produced cooperatively, so scaling is "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` prices the raster kernel against HBM bandwidth
+with the algorithmic bytes of SURVEY.md section 8d (108 B per triangle read once + 28 B per
+pixel written once); its launch duration is measured with HIP events on the frame's own
+stream.  `cpu_baseline` times the CPU oracle in its Version-C shape (OpenMP dynamic loop +
+per-pixel locks) on this host — a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(T, rows, W):
+    return 108 * T + 28 * rows * W
+
+
+def load_traffic(workload):
+    """HBM bytes per raster launch from the committed PMC profile, if one exists."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get(workload, {}).get("raster_hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(tri, col, nrm, H, W, fov, budget_s=12.0):
+    """Version-C-shaped CPU oracle on this host's cores, same frame definition."""
+    from oracle import oracle as O
+    ncpu = os.cpu_count() or 1
+    threads = min(16, ncpu)                      # the README's best column is 16 threads
+    f = O.OracleFiller(H, W, fov=fov, n_threads=threads, mode="omp")
+
+    def frame():
+        f.clear()
+        f.render_arrays(tri, col, nrm)
+
+    t0 = time.perf_counter()
+    frame()                                      # warm-up, also sizes the sample
+    one = time.perf_counter() - t0
+    n = int(max(1, min(200, budget_s / max(one, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        frame()
+    dt = (time.perf_counter() - t0) / n
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "ms_per_frame": dt * 1e3, "host_cpus": ncpu,
+            "sample": f"{n} full frames of the same workload (clear + project + raster), "
+                      f"OpenMP dynamic schedule + per-pixel locks, {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="trex1024",
+                    choices=["cube256", "trex1024", "bunny4096", "trex8192", "synth10m"])
+    ap.add_argument("--synth-triangles", type=int, default=10_000_000)
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from cython3dmodelrenderer_amd import distributed as D
+    from cython3dmodelrenderer_amd import scenes
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N "
+                             "--master-addr 127.0.0.1 bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    tri, col, nrm, (H, W), fov = scenes.scene(args.workload, synth_T=args.synth_triangles)
+    T = int(tri.shape[0])
+    y0, y1 = D.strip_rows(H, world, rank)
+    filler = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile,
+                                       row_strip=(y0, y1) if world > 1 else None)
+    planes = [filler.z_buffer, filler.color_buffer, filler.normals_buffer]
+
+    def step():
+        filler.render_frame()
+        if world > 1 and not args.no_gather:
+            D.all_gather_strips(planes, H, rank, world)
+
+    # upload the model once and make sure the bin lists are large enough (untimed)
+    filler.render_arrays(tri, col, nrm, clear=True)
+    filler.synchronize()
+    for _ in range(args.warmup):
+        step()
+    filler.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    # ---- the timed region: exactly K steps ------------------------------------------
+    filler.timing_begin(args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_timed, bin_ms, raster_ms = filler.timing_end()
+    need, cap = filler.bin_usage()
+    assert need <= cap, "bin lists overflowed inside the timed region"
+
+    if world > 1:
+        t = torch.tensor([elapsed, raster_ms, bin_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, raster_ms, bin_ms = (float(v) for v in t.cpu())
+
+    if rank == 0:
+        fps = args.steps / elapsed
+        rows = y1 - y0                               # this rank's strip (ranks are symmetric)
+        abytes = algorithmic_bytes(T, rows, W)
+        achieved = abytes / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
+        out = {
+            "metric": "frames/sec", "value": fps, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic" if args.workload == "synth10m" else
+            "T-Rex/bunny/cube input arrays committed under tests/golden (made from the reference's "
+            ".obj assets); no dataset download",
+            "config": {"workload": args.workload, "triangles": T, "height": H, "width": W,
+                       "fov": fov, "row_strips": world, "tile": filler.tile or "auto",
+                       "frame": "clear + project + rasterize, model resident in HBM",
+                       "all_gather": bool(world > 1 and not args.no_gather)},
+            "mtris_per_sec": T * fps / 1e6,
+            "frame_algorithmic_bytes": algorithmic_bytes(T, H, W),
+            "whole_frame_gbps": algorithmic_bytes(T, H, W) * fps / 1e9,
+            "kernel_ms": {"binning_passes": bin_ms, "raster": raster_ms, "timed_frames": n_timed},
+            "roofline": {"kernel": "k_raster", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "algorithmic_bytes_per_launch": abytes,
+                         "avg_launch_ms": raster_ms,
+                         "traffic": load_traffic(args.workload)},
+            "bin_entries": {"needed": need, "capacity": cap},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(tri, col, nrm, H, W, fov)
+            out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

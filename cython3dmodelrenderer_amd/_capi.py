@@ -1,0 +1,86 @@
+"""ctypes binding of libcrender_hip.so (C ABI: include/crender_hip.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load, importing
+a symbol from here raises.  Device pointers are plain integers (``tensor.data_ptr()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+ABI_VERSION = 1
+OK, EINVAL, EHIP, ENOMEM = 0, 1, 2, 3
+FUSED_CLEAR = 1
+
+_vp, _i32, _i64, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint, C.c_size_t
+_f32p = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); mirrors include/crender_hip.h one to one
+SIGNATURES = {
+    "crender_abi_version": (_i32, []),
+    "crender_last_error": (C.c_char_p, []),
+    "crender_projection_matrix": (_i32, [C.c_double, C.c_double, C.c_double, _i32, _i32, _f32p]),
+    "crender_project": (_i32, [_vp, _vp, _i64, _f32p, _i32, _i32, _vp]),
+    "crender_clear": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "crender_plan_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i64, _i64, _i32]),
+    "crender_plan_create": (_i32, [C.POINTER(_vp), _i32, _i32, _i32, _i32, _i64, _i64, _i32,
+                                   _vp, _sz, _vp]),
+    "crender_plan_destroy": (None, [_vp]),
+    "crender_plan_last_bin_usage": (_i32, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "crender_plan_timing_begin": (_i32, [_vp, _i32]),
+    "crender_plan_timing_end": (_i32, [_vp, _vp, C.POINTER(_i32), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double)]),
+    "crender_raster": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "crender_render_model": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32p, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "crender_atomic_scratch_bytes": (_sz, [_i32, _i32]),
+    "crender_raster_atomic": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
+                                     _u32, _vp, _vp]),
+    "crender_guro_illumination": (_i32, [_vp, _vp, _f32p, _i32, _i32, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+class CrenderError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """Load the shared library (never builds it: see __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise CrenderError(
+            f"{path} is missing: build it with `python -m cython3dmodelrenderer_amd._build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback for the rasterizer.")
+    L = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = L.crender_abi_version()
+    if got != ABI_VERSION:
+        raise CrenderError(f"libcrender_hip.so ABI {got}, binding expects {ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def check(status: int, what: str):
+    if status != OK:
+        msg = load().crender_last_error()
+        raise CrenderError(f"{what} failed (code {status}): {msg.decode() if msg else ''}")
+
+
+def f32_16(mat):
+    """Host float32[16] ctypes array from a 4x4 numpy matrix."""
+    import numpy as np
+    a = np.ascontiguousarray(mat, dtype=np.float32).reshape(16)
+    return (C.c_float * 16)(*a.tolist())

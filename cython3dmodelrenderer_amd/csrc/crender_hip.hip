@@ -1,0 +1,950 @@
+// crender_hip.hip — gfx950 (MI355X / CDNA4) kernels and the C ABI of include/crender_hip.h.
+//
+// Frame = K1 (projection) + K2 (rasterization) of the reference's
+// AdvancedPixelBufferFiller.render_model (.pyx:92-244), restructured for the GPU:
+//
+//   k_setup   one thread per triangle: [project,] back-face cull, pixel box, tile range;
+//             per-tile list lengths counted in an LDS histogram, flushed with one
+//             global atomic per (block, touched tile).
+//   k_scan    one workgroup: exclusive scan of the tile list lengths.
+//   k_fill    writes triangle indices into the tile lists (block-private LDS cursors,
+//             one global atomic per (block, touched tile) to reserve list space).
+//   k_raster  one workgroup per screen tile: a 64-bit (z, index) key per pixel lives in
+//             LDS; 16-lane groups sweep small pixel boxes and whole wavefronts sweep
+//             large ones with LDS atomic-min; then every pixel recomputes its winning
+//             fragment and stores z / colour / normal once (the clear is fused).
+//
+// No HBM atomics on the framebuffer and every framebuffer byte is written once per
+// frame.  Build flags (see _build.py): -ffp-contract=off, correctly rounded division,
+// denormals on — float parity with the reference depends on them.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/crender_hip.h"
+#include "raster_math.h"
+
+using namespace crender;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *what)
+{
+    g_last_error = what;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *where)
+{
+    g_last_error = std::string(where) + ": " + hipGetErrorString(e);
+    return CRENDER_EHIP;
+}
+
+#define CR_HIP(expr)                                             \
+    do {                                                         \
+        hipError_t _e = (expr);                                  \
+        if (_e != hipSuccess) return fail_hip(_e, #expr);        \
+    } while (0)
+
+#define CR_LAUNCH_CHECK(name)                                    \
+    do {                                                         \
+        hipError_t _e = hipGetLastError();                       \
+        if (_e != hipSuccess) return fail_hip(_e, name);         \
+    } while (0)
+
+constexpr int kThreads = 256;           // 4 wavefronts per workgroup
+constexpr uint32_t kNoTiles = 0xFFFFFFFFu;
+
+// Strip geometry shared by the binning and raster kernels.
+struct Geom {
+    int W, H;      // full frame
+    int y0, y1;    // strip rows
+    int ntx, nty;  // tiles across / down the strip
+    int ntiles;
+};
+
+ProjConst make_proj(const float *P16, int w, int h)
+{
+    ProjConst P;
+    std::memcpy(P.p, P16, sizeof P.p);
+    P.xs = (float)((double)w / 2.0);   // .pyx:109
+    P.ys = (float)((double)h / 2.0);
+    return P;
+}
+
+// ---- coalesced staging of [n][9] float chunks through LDS -------------------------
+// Triangle records are 36 B, so per-thread vector loads would be misaligned; a block
+// copies its contiguous chunk with unit-stride loads and each thread then reads its own
+// record at a 9-dword stride (odd => conflict-free across the 32 banks).
+CR_DEV void stage_in(const float *__restrict__ g, float *__restrict__ s, int nfloats)
+{
+    const bool aligned = (((uintptr_t)g) & 15u) == 0;
+    if (aligned) {
+        const int n4 = nfloats >> 2;
+        const float4 *g4 = reinterpret_cast<const float4 *>(g);
+        float4 *s4 = reinterpret_cast<float4 *>(s);
+        for (int i = threadIdx.x; i < n4; i += kThreads) s4[i] = g4[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < nfloats; i += kThreads) s[i] = g[i];
+    } else {
+        for (int i = threadIdx.x; i < nfloats; i += kThreads) s[i] = g[i];
+    }
+}
+
+CR_DEV void stage_out(float *__restrict__ g, const float *__restrict__ s, int nfloats)
+{
+    const bool aligned = (((uintptr_t)g) & 15u) == 0;
+    if (aligned) {
+        const int n4 = nfloats >> 2;
+        float4 *g4 = reinterpret_cast<float4 *>(g);
+        const float4 *s4 = reinterpret_cast<const float4 *>(s);
+        for (int i = threadIdx.x; i < n4; i += kThreads) g4[i] = s4[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < nfloats; i += kThreads) g[i] = s[i];
+    } else {
+        for (int i = threadIdx.x; i < nfloats; i += kThreads) g[i] = s[i];
+    }
+}
+
+// ---- K1 standalone: project_on_screen_multithread, .pyx:106-130 -------------------
+__global__ __launch_bounds__(kThreads) void k_project(const float *__restrict__ in,
+                                                      float *__restrict__ out, int64_t T,
+                                                      ProjConst P)
+{
+    __shared__ __attribute__((aligned(16))) float s[kThreads * 9];
+    for (int64_t b0 = (int64_t)blockIdx.x * kThreads; b0 < T; b0 += (int64_t)gridDim.x * kThreads) {
+        const int n = (int)((T - b0) < kThreads ? (T - b0) : kThreads);
+        stage_in(in + b0 * 9, s, n * 9);
+        __syncthreads();
+        if ((int)threadIdx.x < n) {
+            float *v = s + threadIdx.x * 9;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float r[3] = {v[3 * c], v[3 * c + 1], v[3 * c + 2]};
+                project_vertex(P, r);
+                v[3 * c] = r[0];
+                v[3 * c + 1] = r[1];
+                v[3 * c + 2] = r[2];
+            }
+        }
+        __syncthreads();
+        stage_out(out + b0 * 9, s, n * 9);
+        __syncthreads();
+    }
+}
+
+// ---- clear: __cinit__ buffer state, .pyx:65-67 ------------------------------------
+__global__ __launch_bounds__(kThreads) void k_clear(float *__restrict__ zb, float *__restrict__ cb,
+                                                    float *__restrict__ nb, int32_t *__restrict__ win,
+                                                    size_t first_pix, size_t npix)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < npix; i += stride) {
+        zb[first_pix + i] = 1e6f;
+        if (win) win[first_pix + i] = -1;
+    }
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < npix * 3; i += stride) {
+        cb[first_pix * 3 + i] = 0.0f;
+        nb[first_pix * 3 + i] = 0.0f;
+    }
+}
+
+// ---- binning ----------------------------------------------------------------------
+// Tile range of a triangle packed as tx0 | tx1 << 16 (x) and ty0 | ty1 << 16 (y),
+// inclusive; kNoTiles in .x marks a culled / empty triangle.
+template <int TS>
+CR_DEV uint2 tile_range(const TriXYZ &t, const Geom &G)
+{
+    int xl, xr, yt, yb;
+    pixel_box(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2, G.W, G.H, xl, xr, yt, yb);
+    // .pyx:209 skips an empty box; rows outside the strip never produce samples.
+    if (yt < G.y0) yt = G.y0;
+    if (yb > G.y1) yb = G.y1;
+    if (xl >= xr || yt >= yb) return make_uint2(kNoTiles, 0);
+    const uint32_t tx0 = xl / TS, tx1 = (xr - 1) / TS;
+    const uint32_t ty0 = (yt - G.y0) / TS, ty1 = (yb - 1 - G.y0) / TS;
+    return make_uint2(tx0 | (tx1 << 16), ty0 | (ty1 << 16));
+}
+
+// dynamic LDS: [hist: ntiles u32 if LDS_HIST][verts: 256*9 f32][normals: 256*9 f32]
+template <int TS, bool PROJECT, bool LDS_HIST>
+__global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tri_in,
+                                                    const float *__restrict__ nrm,
+                                                    float *__restrict__ proj_out,
+                                                    uint2 *__restrict__ trange,
+                                                    uint32_t *__restrict__ count, int64_t T,
+                                                    int64_t chunk, ProjConst P, Geom G)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int hist_words = LDS_HIST ? ((G.ntiles + 3) & ~3) : 0;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw);
+    float *sv = reinterpret_cast<float *>(smem_raw) + hist_words;
+    float *sn = sv + kThreads * 9;
+
+    if (LDS_HIST) {
+        for (int i = threadIdx.x; i < G.ntiles; i += kThreads) hist[i] = 0;
+    }
+    const int64_t c0 = (int64_t)blockIdx.x * chunk;
+    const int64_t c1 = (c0 + chunk < T) ? (c0 + chunk) : T;
+    __syncthreads();
+    for (int64_t b0 = c0; b0 < c1; b0 += kThreads) {
+        const int n = (int)((c1 - b0) < kThreads ? (c1 - b0) : kThreads);
+        stage_in(tri_in + b0 * 9, sv, n * 9);
+        stage_in(nrm + b0 * 9, sn, n * 9);
+        __syncthreads();
+        if ((int)threadIdx.x < n) {
+            float *v = sv + threadIdx.x * 9;
+            const float *nn = sn + threadIdx.x * 9;
+            float a[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a[i] = v[i];
+            if (PROJECT) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) project_vertex(P, a + 3 * c);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) v[i] = a[i];
+            }
+            uint2 r = make_uint2(kNoTiles, 0);
+            if (!backface(nn[2], nn[5], nn[8])) {
+                const TriXYZ t{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]};
+                r = tile_range<TS>(t, G);
+            }
+            trange[b0 + threadIdx.x] = r;
+            if (r.x != kNoTiles) {
+                const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
+                for (int ty = ty0; ty <= ty1; ++ty)
+                    for (int tx = tx0; tx <= tx1; ++tx) {
+                        if (LDS_HIST) atomicAdd(&hist[ty * G.ntx + tx], 1u);
+                        else atomicAdd(&count[ty * G.ntx + tx], 1u);
+                    }
+            }
+        }
+        __syncthreads();
+        if (PROJECT) {
+            stage_out(proj_out + b0 * 9, sv, n * 9);
+            __syncthreads();
+        }
+    }
+    if (LDS_HIST) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < G.ntiles; i += kThreads) {
+            const uint32_t c = hist[i];
+            if (c) atomicAdd(&count[i], c);
+        }
+    }
+}
+
+// Exclusive scan of count[0..ntiles) into offs[0..ntiles]; count is zeroed (k_fill uses
+// it as the per-tile cursor); hdr[0] = total number of list entries this frame needs.
+__global__ __launch_bounds__(1024) void k_scan(uint32_t *__restrict__ count,
+                                               uint32_t *__restrict__ offs,
+                                               uint32_t *__restrict__ hdr, int ntiles)
+{
+    __shared__ uint32_t part[1024];
+    const int per = (ntiles + 1023) / 1024;
+    const int b = threadIdx.x * per;
+    const int e = (b + per < ntiles) ? (b + per) : ntiles;
+    uint32_t s = 0;
+    for (int i = b; i < e; ++i) s += count[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 partial sums
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (int i = b; i < e; ++i) {
+        const uint32_t c = count[i];
+        offs[i] = run;
+        run += c;
+        count[i] = 0;
+    }
+    if (threadIdx.x == 1023) {
+        offs[ntiles] = part[1023];
+        hdr[0] = part[1023];
+    }
+}
+
+// dynamic LDS: [cur: ntiles u32] when LDS_HIST
+template <bool LDS_HIST>
+__global__ __launch_bounds__(kThreads) void k_fill(const uint2 *__restrict__ trange,
+                                                   const uint32_t *__restrict__ offs,
+                                                   uint32_t *__restrict__ cursor,
+                                                   uint32_t *__restrict__ entries,
+                                                   uint32_t capacity, int64_t T, int64_t chunk,
+                                                   Geom G)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *cur = reinterpret_cast<uint32_t *>(smem_raw);
+    const int64_t c0 = (int64_t)blockIdx.x * chunk;
+    const int64_t c1 = (c0 + chunk < T) ? (c0 + chunk) : T;
+    if (LDS_HIST) {
+        for (int i = threadIdx.x; i < G.ntiles; i += kThreads) cur[i] = 0;
+        __syncthreads();
+        // sweep 1: how many entries this block adds to each tile list
+        for (int64_t t = c0 + threadIdx.x; t < c1; t += kThreads) {
+            const uint2 r = trange[t];
+            if (r.x == kNoTiles) continue;
+            const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cur[ty * G.ntx + tx], 1u);
+        }
+        __syncthreads();
+        // reserve a contiguous run in every touched list
+        for (int i = threadIdx.x; i < G.ntiles; i += kThreads) {
+            const uint32_t c = cur[i];
+            if (c) cur[i] = offs[i] + atomicAdd(&cursor[i], c);
+        }
+        __syncthreads();
+    }
+    for (int64_t t = c0 + threadIdx.x; t < c1; t += kThreads) {
+        const uint2 r = trange[t];
+        if (r.x == kNoTiles) continue;
+        const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) {
+                const int tile = ty * G.ntx + tx;
+                uint32_t pos;
+                if (LDS_HIST) pos = atomicAdd(&cur[tile], 1u);
+                else pos = offs[tile] + atomicAdd(&cursor[tile], 1u);
+                if (pos < capacity) entries[pos] = (uint32_t)t;
+            }
+    }
+}
+
+// ---- tile rasterizer --------------------------------------------------------------
+// Work record of one (tile, triangle) pair, struct-of-arrays in LDS.
+struct WorkQueue {
+    float x0[kThreads], y0[kThreads], z0[kThreads];
+    float x1[kThreads], y1[kThreads], z1[kThreads];
+    float x2[kThreads], y2[kThreads], z2[kThreads];
+    uint32_t tri[kThreads];
+    uint32_t box_xy[kThreads];  // bx0 | by0 << 16  (frame pixel coordinates)
+    uint32_t box_wh[kThreads];  // bw  | bh  << 16
+};
+
+// XCD-aware block -> tile map: workgroups are dealt round-robin over the 8 XCDs, so
+// block b and b + 8 share an L2.  Give each XCD one contiguous band of tiles so that
+// neighbouring tiles, which share triangles, hit the same L2.  Speed only.
+CR_DEV int xcd_band_tile(int b, int n)
+{
+    const int per = n >> 3, rem = n & 7;
+    const int xcd = b & 7, k = b >> 3;
+    return xcd * per + (xcd < rem ? xcd : rem) + k;
+}
+
+// Lower an LDS depth key.  The relaxed atomic load is one ds_read_b64 (never torn); keys
+// only ever decrease, so a fragment that is not below the value read can be dropped.
+CR_DEV void lds_key_min(unsigned long long *slot, unsigned long long k)
+{
+    if (k < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMin(slot, k);
+}
+
+template <int TS, bool CLEAR>
+__global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ proj,
+                                                     const float *__restrict__ col,
+                                                     const float *__restrict__ nrm,
+                                                     const uint32_t *__restrict__ offs,
+                                                     uint32_t *__restrict__ cursor,
+                                                     const uint32_t *__restrict__ entries,
+                                                     uint32_t capacity, float *__restrict__ zb,
+                                                     float *__restrict__ cb, float *__restrict__ nb,
+                                                     int32_t *__restrict__ win, Geom G)
+{
+    __shared__ unsigned long long key[TS * TS];
+    __shared__ WorkQueue q;
+    // queue fill counters, double-buffered by batch parity so that two barriers per
+    // batch suffice: [parity][0] = small boxes, [parity][1] = large boxes
+    __shared__ uint32_t q_count[2][2];
+
+    const int tile = xcd_band_tile(blockIdx.x, G.ntiles);
+    const int tx = tile % G.ntx, ty = tile / G.ntx;
+    const int X0 = tx * TS, Y0 = G.y0 + ty * TS;
+    const int X1 = (X0 + TS < G.W) ? (X0 + TS) : G.W;
+    const int Y1 = (Y0 + TS < G.y1) ? (Y0 + TS) : G.y1;
+    const int tid = threadIdx.x;
+
+    // depth keys of the tile: the prior buffer value (or the cleared value) per pixel
+    const unsigned long long key_clear = make_key(zord(1e6f), KEY_LOW_PRIOR);
+    for (int p = tid; p < TS * TS; p += kThreads) {
+        unsigned long long k = key_clear;
+        if (!CLEAR) {
+            const int x = X0 + (p % TS), y = Y0 + (p / TS);
+            if (x < X1 && y < Y1) k = make_key(zord_prior(zb[(size_t)y * G.W + x]), KEY_LOW_PRIOR);
+        }
+        key[p] = k;
+    }
+
+    uint32_t beg = offs[tile], end = offs[tile + 1];
+    if (end > capacity) end = capacity;
+    if (beg > end) beg = end;
+    if (tid == 0) {
+        cursor[tile] = 0;  // restore the all-zero invariant for the next frame
+        q_count[0][0] = q_count[0][1] = q_count[1][0] = q_count[1][1] = 0;
+    }
+    __syncthreads();  // keys and counters initialised
+
+    int parity = 0;
+    for (uint32_t base = beg; base < end; base += kThreads, parity ^= 1) {
+        uint32_t &n_small = q_count[parity][0], &n_large = q_count[parity][1];
+        const uint32_t i = base + tid;
+        if (i < end) {
+            const uint32_t id = entries[i];
+            const TriXYZ t = load_tri(proj + (size_t)id * 9);
+            int xl, xr, yt, yb;
+            pixel_box(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2, G.W, G.H, xl, xr, yt, yb);
+            if (xl < X0) xl = X0;
+            if (xr > X1) xr = X1;
+            if (yt < Y0) yt = Y0;
+            if (yb > Y1) yb = Y1;
+            if (xl < xr && yt < yb) {
+                const int bw = xr - xl, bh = yb - yt;
+                // small boxes fill the queue from the front, large ones from the back
+                uint32_t slot;
+                if (bw <= 8 && bh <= 8) slot = atomicAdd(&n_small, 1u);
+                else slot = kThreads - 1 - atomicAdd(&n_large, 1u);
+                q.x0[slot] = t.x0; q.y0[slot] = t.y0; q.z0[slot] = t.z0;
+                q.x1[slot] = t.x1; q.y1[slot] = t.y1; q.z1[slot] = t.z1;
+                q.x2[slot] = t.x2; q.y2[slot] = t.y2; q.z2[slot] = t.z2;
+                q.tri[slot] = id;
+                q.box_xy[slot] = (uint32_t)xl | ((uint32_t)yt << 16);
+                q.box_wh[slot] = (uint32_t)bw | ((uint32_t)bh << 16);
+            }
+        }
+        __syncthreads();  // queue complete
+        const int ns = (int)n_small, nl = (int)n_large;
+        // the other parity's counters were last read before the previous batch's closing
+        // barrier and are next written after this batch's closing barrier
+        if (tid == 0) q_count[parity ^ 1][0] = q_count[parity ^ 1][1] = 0;
+
+        // small boxes: one 16-lane group per record, 4x4 pixel steps
+        {
+            const int grp = tid >> 4, l = tid & 15, lx = l & 3, ly = l >> 2;
+            for (int r = grp; r < ns; r += kThreads / 16) {
+                const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
+                               q.x2[r], q.y2[r], q.z2[r]};
+                const uint32_t id = q.tri[r];
+                const int bx0 = q.box_xy[r] & 0xFFFF, by0 = q.box_xy[r] >> 16;
+                const int bx1 = bx0 + (int)(q.box_wh[r] & 0xFFFF), by1 = by0 + (int)(q.box_wh[r] >> 16);
+                for (int yy = by0 + ly; yy < by1; yy += 4)
+                    for (int xx = bx0 + lx; xx < bx1; xx += 4) {
+                        unsigned long long k;
+                        if (fragment(t, id, xx, yy, k)) {
+                            lds_key_min(&key[(yy - Y0) * TS + (xx - X0)], k);
+                        }
+                    }
+            }
+        }
+        // large boxes: one wavefront per record, 8x8 pixel steps
+        {
+            const int wave = tid >> 6, l = tid & 63, lx = l & 7, ly = l >> 3;
+            for (int j = wave; j < nl; j += kThreads / 64) {
+                const int r = kThreads - 1 - j;
+                const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
+                               q.x2[r], q.y2[r], q.z2[r]};
+                const uint32_t id = q.tri[r];
+                const int bx0 = q.box_xy[r] & 0xFFFF, by0 = q.box_xy[r] >> 16;
+                const int bx1 = bx0 + (int)(q.box_wh[r] & 0xFFFF), by1 = by0 + (int)(q.box_wh[r] >> 16);
+                for (int yy = by0 + ly; yy < by1; yy += 8)
+                    for (int xx = bx0 + lx; xx < bx1; xx += 8) {
+                        unsigned long long k;
+                        if (fragment(t, id, xx, yy, k)) {
+                            lds_key_min(&key[(yy - Y0) * TS + (xx - X0)], k);
+                        }
+                    }
+            }
+        }
+        __syncthreads();  // sweeps done: the next batch may overwrite the queue
+    }
+
+    // resolve: every pixel of the tile is written at most once (exactly once if CLEAR)
+    for (int p = tid; p < TS * TS; p += kThreads) {
+        const int x = X0 + (p % TS), y = Y0 + (p / TS);
+        if (x >= X1 || y >= Y1) continue;
+        const size_t pix = (size_t)y * G.W + x;
+        const uint32_t low = (uint32_t)key[p];
+        if (low == KEY_LOW_PRIOR) {
+            if (CLEAR) {
+                zb[pix] = 1e6f;
+                cb[pix * 3] = 0.0f; cb[pix * 3 + 1] = 0.0f; cb[pix * 3 + 2] = 0.0f;
+                nb[pix * 3] = 0.0f; nb[pix * 3 + 1] = 0.0f; nb[pix * 3 + 2] = 0.0f;
+                if (win) win[pix] = -1;
+            }
+            continue;
+        }
+        const uint32_t id = 0xFFFFFFFEu - low;
+        shade_and_store(proj, col, nrm, id, x, y, pix, zb, cb, nb);
+        if (win) win[pix] = (int32_t)id;
+    }
+}
+
+// ---- second implementation: global 64-bit atomics ---------------------------------
+__global__ __launch_bounds__(kThreads) void k_keys_init(unsigned long long *__restrict__ keys,
+                                                        const float *__restrict__ zb,
+                                                        size_t first_pix, size_t npix, int clear)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    const unsigned long long key_clear = make_key(zord(1e6f), KEY_LOW_PRIOR);
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < npix; i += stride)
+        keys[first_pix + i] = clear ? key_clear : make_key(zord_prior(zb[first_pix + i]), KEY_LOW_PRIOR);
+}
+
+// one wavefront per triangle, 8x8 pixel steps over the pixel box
+__global__ __launch_bounds__(kThreads) void k_cover_atomic(const float *__restrict__ proj,
+                                                           const float *__restrict__ nrm,
+                                                           unsigned long long *__restrict__ keys,
+                                                           int64_t T, int W, int H, int y0, int y1)
+{
+    const int l = threadIdx.x & 63, lx = l & 7, ly = l >> 3;
+    const int64_t wave = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kThreads) >> 6;
+    for (int64_t t = wave; t < T; t += nwaves) {
+        const float *nn = nrm + t * 9;
+        if (backface(nn[2], nn[5], nn[8])) continue;
+        const TriXYZ tr = load_tri(proj + t * 9);
+        int xl, xr, yt, yb;
+        pixel_box(tr.x0, tr.y0, tr.x1, tr.y1, tr.x2, tr.y2, W, H, xl, xr, yt, yb);
+        if (xl - xr == 0 || yt - yb == 0) continue;  // .pyx:209
+        if (yt < y0) yt = y0;
+        if (yb > y1) yb = y1;
+        for (int yy = yt + ly; yy < yb; yy += 8)
+            for (int xx = xl + lx; xx < xr; xx += 8) {
+                unsigned long long k;
+                if (fragment(tr, (uint32_t)t, xx, yy, k)) {
+                    unsigned long long *slot = &keys[(size_t)yy * W + xx];
+                    if (k < *slot) atomicMin(slot, k);
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_resolve_global(const float *__restrict__ proj,
+                                                             const float *__restrict__ col,
+                                                             const float *__restrict__ nrm,
+                                                             const unsigned long long *__restrict__ keys,
+                                                             float *__restrict__ zb, float *__restrict__ cb,
+                                                             float *__restrict__ nb, int32_t *__restrict__ win,
+                                                             int W, size_t first_pix, size_t npix, int clear)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < npix; i += stride) {
+        const size_t pix = first_pix + i;
+        const uint32_t low = (uint32_t)keys[pix];
+        if (low == KEY_LOW_PRIOR) {
+            if (clear) {
+                zb[pix] = 1e6f;
+                cb[pix * 3] = 0.0f; cb[pix * 3 + 1] = 0.0f; cb[pix * 3 + 2] = 0.0f;
+                nb[pix * 3] = 0.0f; nb[pix * 3 + 1] = 0.0f; nb[pix * 3 + 2] = 0.0f;
+                if (win) win[pix] = -1;
+            }
+            continue;
+        }
+        const uint32_t id = 0xFFFFFFFEu - low;
+        shade_and_store(proj, col, nrm, id, (int)(pix % W), (int)(pix / W), pix, zb, cb, nb);
+        if (win) win[pix] = (int32_t)id;
+    }
+}
+
+// ---- f1: Guro illumination, guro_illumination.py:20-27 ----------------------------
+// numpy evaluates, in float32: s = sum_k(n_k * l_k); m = sqrt(sum_k(n_k * n_k));
+// c = clip(s / (m + 1e-6f), 0, 1); colour *= c.  A 3-element float32 add.reduce over the
+// last axis runs left to right, (a0 + a1) + a2 (checked against numpy 2.2 in
+// tests/test_host_cpu.py::test_numpy_three_element_sum_order).
+__global__ __launch_bounds__(kThreads) void k_guro(float *__restrict__ cb, const float *__restrict__ nb,
+                                                   float l0, float l1, float l2,
+                                                   size_t first_pix, size_t npix)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < npix; i += stride) {
+        const size_t pix = first_pix + i;
+        const float n0 = nb[pix * 3], n1 = nb[pix * 3 + 1], n2 = nb[pix * 3 + 2];
+        const float s = (n0 * l0 + n1 * l1) + n2 * l2;
+        const float m = sqrtf((n0 * n0 + n1 * n1) + n2 * n2);
+        float c = s / (m + 1e-6f);
+        c = c < 0.0f ? 0.0f : c;  // np.clip keeps a NaN a NaN
+        c = c > 1.0f ? 1.0f : c;
+        cb[pix * 3] *= c;
+        cb[pix * 3 + 1] *= c;
+        cb[pix * 3 + 2] *= c;
+    }
+}
+
+// ---- host side --------------------------------------------------------------------
+constexpr size_t kAlign = 256;
+size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
+
+int pick_tile(int H, int W, int tile)
+{
+    if (tile == 32 || tile == 64) return tile;
+    return ((int64_t)H * W <= (int64_t)2048 * 2048) ? 32 : 64;
+}
+
+struct Layout {
+    int ts;
+    Geom g;
+    int64_t max_T;
+    int64_t capacity;
+    size_t off_hdr, off_count, off_offs, off_trange, off_proj, off_entries, total;
+};
+
+bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int tile, Layout &L)
+{
+    if (H <= 0 || W <= 0 || y0 < 0 || y1 > H || y0 >= y1 || max_T < 0) return false;
+    if (W > 65535 || H > 65535) return false;             // pixel boxes are packed in 16 bits
+    if (max_T > 0xFFFFFFF0ll) return false;               // triangle index lives in 32 key bits
+    L.ts = pick_tile(H, W, tile);
+    L.g.W = W; L.g.H = H; L.g.y0 = y0; L.g.y1 = y1;
+    L.g.ntx = (W + L.ts - 1) / L.ts;
+    L.g.nty = (y1 - y0 + L.ts - 1) / L.ts;
+    L.g.ntiles = L.g.ntx * L.g.nty;
+    L.max_T = max_T;
+    if (cap <= 0) cap = 4 * max_T + 4 * (int64_t)L.g.ntiles + 65536;
+    if (cap > 0xFFFFFFF0ll) cap = 0xFFFFFFF0ll;
+    L.capacity = cap;
+    size_t o = 0;
+    L.off_hdr = o;     o = align_up(o + 64);
+    L.off_count = o;   o = align_up(o + sizeof(uint32_t) * (size_t)(L.g.ntiles + 1));
+    L.off_offs = o;    o = align_up(o + sizeof(uint32_t) * (size_t)(L.g.ntiles + 1));
+    L.off_trange = o;  o = align_up(o + sizeof(uint2) * (size_t)max_T);
+    L.off_proj = o;    o = align_up(o + sizeof(float) * 9 * (size_t)max_T);
+    L.off_entries = o; o = align_up(o + sizeof(uint32_t) * (size_t)cap);
+    L.total = o;
+    return true;
+}
+
+}  // namespace
+
+struct crender_plan {
+    Layout L;
+    unsigned char *ws;
+    // optional per-frame HIP events (crender_plan_timing_begin): 3 per frame —
+    // before the binning passes, before k_raster, after k_raster
+    std::vector<hipEvent_t> events;
+    int timed_frames = 0;
+    bool timing() const { return !events.empty() && (size_t)(timed_frames + 1) * 3 <= events.size(); }
+    hipEvent_t ev(int k) const { return events[(size_t)timed_frames * 3 + k]; }
+    uint32_t *hdr() const { return reinterpret_cast<uint32_t *>(ws + L.off_hdr); }
+    uint32_t *count() const { return reinterpret_cast<uint32_t *>(ws + L.off_count); }
+    uint32_t *offs() const { return reinterpret_cast<uint32_t *>(ws + L.off_offs); }
+    uint2 *trange() const { return reinterpret_cast<uint2 *>(ws + L.off_trange); }
+    float *proj() const { return reinterpret_cast<float *>(ws + L.off_proj); }
+    uint32_t *entries() const { return reinterpret_cast<uint32_t *>(ws + L.off_entries); }
+};
+
+namespace {
+
+int grid_for(size_t items, int cap)
+{
+    size_t b = (items + kThreads - 1) / kThreads;
+    if (b < 1) b = 1;
+    if (b > (size_t)cap) b = (size_t)cap;
+    return (int)b;
+}
+
+// LDS histogram of the tile lists fits next to the staging buffers up to this many tiles.
+constexpr int kMaxLdsHistTiles = 8192;  // 32 KiB histogram + 18 KiB staging < 64 KiB
+
+template <int TS>
+int run_tile_frame(crender_plan *plan, bool project, const float *d_tri, const float *d_col,
+                   const float *d_nrm, int64_t T, const ProjConst &P, float *d_z, float *d_color,
+                   float *d_normal, int32_t *d_winner, unsigned flags, hipStream_t s)
+{
+    const Layout &L = plan->L;
+    const Geom G = L.g;
+    const float *proj = project ? plan->proj() : d_tri;
+    const bool timing = plan->timing();
+    if (timing) CR_HIP(hipEventRecord(plan->ev(0), s));
+    if (T > 0) {
+        // contiguous chunk of triangles per block, a multiple of the block size
+        int64_t nblk = (T + kThreads - 1) / kThreads;
+        if (nblk > 2048) nblk = 2048;
+        int64_t chunk = (T + nblk - 1) / nblk;
+        chunk = (chunk + kThreads - 1) / kThreads * kThreads;
+        nblk = (T + chunk - 1) / chunk;
+        const bool lds_hist = G.ntiles <= kMaxLdsHistTiles;
+        const size_t hist_bytes = lds_hist ? sizeof(uint32_t) * (size_t)((G.ntiles + 3) & ~3) : 0;
+        const size_t setup_lds = hist_bytes + sizeof(float) * kThreads * 9 * 2;
+#define CR_SETUP(PROJ, HIST)                                                                       \
+    hipLaunchKernelGGL((k_setup<TS, PROJ, HIST>), dim3((unsigned)nblk), dim3(kThreads), setup_lds, \
+                       s, d_tri, d_nrm, plan->proj(), plan->trange(), plan->count(), T, chunk, P, G)
+        if (project) { if (lds_hist) CR_SETUP(true, true); else CR_SETUP(true, false); }
+        else         { if (lds_hist) CR_SETUP(false, true); else CR_SETUP(false, false); }
+#undef CR_SETUP
+        CR_LAUNCH_CHECK("k_setup");
+    }
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, plan->count(), plan->offs(), plan->hdr(),
+                       G.ntiles);
+    CR_LAUNCH_CHECK("k_scan");
+    if (T > 0) {
+        int64_t nblk = (T + kThreads - 1) / kThreads;
+        if (nblk > 1024) nblk = 1024;
+        int64_t chunk = (T + nblk - 1) / nblk;
+        chunk = (chunk + kThreads - 1) / kThreads * kThreads;
+        nblk = (T + chunk - 1) / chunk;
+        const bool lds_hist = G.ntiles <= kMaxLdsHistTiles;
+        const size_t lds = lds_hist ? sizeof(uint32_t) * (size_t)G.ntiles : 0;
+        if (lds_hist)
+            hipLaunchKernelGGL((k_fill<true>), dim3((unsigned)nblk), dim3(kThreads), lds, s,
+                               plan->trange(), plan->offs(), plan->count(), plan->entries(),
+                               (uint32_t)L.capacity, T, chunk, G);
+        else
+            hipLaunchKernelGGL((k_fill<false>), dim3((unsigned)nblk), dim3(kThreads), 0, s,
+                               plan->trange(), plan->offs(), plan->count(), plan->entries(),
+                               (uint32_t)L.capacity, T, chunk, G);
+        CR_LAUNCH_CHECK("k_fill");
+    }
+    if (timing) CR_HIP(hipEventRecord(plan->ev(1), s));
+    if (flags & CRENDER_FUSED_CLEAR)
+        hipLaunchKernelGGL((k_raster<TS, true>), dim3((unsigned)G.ntiles), dim3(kThreads), 0, s, proj,
+                           d_col, d_nrm, plan->offs(), plan->count(), plan->entries(),
+                           (uint32_t)L.capacity, d_z, d_color, d_normal, d_winner, G);
+    else
+        hipLaunchKernelGGL((k_raster<TS, false>), dim3((unsigned)G.ntiles), dim3(kThreads), 0, s, proj,
+                           d_col, d_nrm, plan->offs(), plan->count(), plan->entries(),
+                           (uint32_t)L.capacity, d_z, d_color, d_normal, d_winner, G);
+    CR_LAUNCH_CHECK("k_raster");
+    if (timing) {
+        CR_HIP(hipEventRecord(plan->ev(2), s));
+        plan->timed_frames++;
+    }
+    return CRENDER_OK;
+}
+
+int tile_frame(crender_plan *plan, bool project, const float *d_tri, const float *d_col,
+               const float *d_nrm, int64_t T, const float *P16, float *d_z, float *d_color,
+               float *d_normal, int32_t *d_winner, unsigned flags, void *stream)
+{
+    if (!plan) return fail(CRENDER_EINVAL, "null plan");
+    if (T < 0 || T > plan->L.max_T) return fail(CRENDER_EINVAL, "T exceeds the plan's max_T");
+    if (!d_z || !d_color || !d_normal) return fail(CRENDER_EINVAL, "null framebuffer pointer");
+    if (T > 0 && (!d_tri || !d_col || !d_nrm)) return fail(CRENDER_EINVAL, "null triangle array");
+    if (project && !P16) return fail(CRENDER_EINVAL, "null projection matrix");
+    ProjConst P;
+    std::memset(&P, 0, sizeof P);
+    if (project) P = make_proj(P16, plan->L.g.W, plan->L.g.H);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (plan->L.ts == 32)
+        return run_tile_frame<32>(plan, project, d_tri, d_col, d_nrm, T, P, d_z, d_color, d_normal,
+                                  d_winner, flags, s);
+    return run_tile_frame<64>(plan, project, d_tri, d_col, d_nrm, T, P, d_z, d_color, d_normal,
+                              d_winner, flags, s);
+}
+
+}  // namespace
+
+// =========================== C ABI ================================================
+extern "C" {
+
+int crender_abi_version(void) { return CRENDER_ABI_VERSION; }
+
+const char *crender_last_error(void) { return g_last_error.c_str(); }
+
+int crender_projection_matrix(double fov_deg, double z_near, double z_far, int h, int w, float *P16)
+{
+    if (!P16 || h <= 0 || w <= 0) return fail(CRENDER_EINVAL, "crender_projection_matrix: bad argument");
+    // .pyx:54-59: fov -> C float; f evaluated in double from that float, stored as float
+    const float fovf = (float)fov_deg;
+    const float f = (float)(1.0 / std::tan((double)fovf / 2 / 180 * M_PI));
+    const float zn = (float)z_near, zf = (float)z_far;
+    const float a = (float)((double)h / (double)w);
+    // .pyx:83-90: q and f/a in float arithmetic; -z_near*q = exact double product of two
+    // floats rounded once to float32
+    const float q = zf / (zf - zn);
+    std::memset(P16, 0, 16 * sizeof(float));
+    P16[0] = f / a;
+    P16[5] = f;
+    P16[10] = q;
+    P16[11] = 1.0f;
+    P16[14] = (float)((double)(-zn) * (double)q);
+    return CRENDER_OK;
+}
+
+int crender_project(const float *d_tri_in, float *d_tri_out, int64_t T, const float *P16, int w,
+                    int h, void *stream)
+{
+    if (T < 0 || !P16 || w <= 0 || h <= 0) return fail(CRENDER_EINVAL, "crender_project: bad argument");
+    if (T == 0) return CRENDER_OK;
+    if (!d_tri_in || !d_tri_out) return fail(CRENDER_EINVAL, "crender_project: null array");
+    const ProjConst P = make_proj(P16, w, h);
+    hipLaunchKernelGGL(k_project, dim3(grid_for((size_t)T, 4096)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), d_tri_in, d_tri_out, T, P);
+    CR_LAUNCH_CHECK("k_project");
+    return CRENDER_OK;
+}
+
+int crender_clear(float *d_z, float *d_color, float *d_normal, int32_t *d_winner, int H, int W, int y0,
+                  int y1, void *stream)
+{
+    if (!d_z || !d_color || !d_normal || H <= 0 || W <= 0 || y0 < 0 || y1 > H || y0 >= y1)
+        return fail(CRENDER_EINVAL, "crender_clear: bad argument");
+    const size_t first = (size_t)y0 * W, npix = (size_t)(y1 - y0) * W;
+    hipLaunchKernelGGL(k_clear, dim3(grid_for(npix * 3, 4096)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), d_z, d_color, d_normal, d_winner, first, npix);
+    CR_LAUNCH_CHECK("k_clear");
+    return CRENDER_OK;
+}
+
+size_t crender_plan_workspace_bytes(int H, int W, int y0, int y1, int64_t max_T, int64_t bin_capacity,
+                                    int tile)
+{
+    Layout L;
+    if (!make_layout(H, W, y0, y1, max_T, bin_capacity, tile, L)) return 0;
+    return L.total;
+}
+
+int crender_plan_create(crender_plan **out, int H, int W, int y0, int y1, int64_t max_T,
+                        int64_t bin_capacity, int tile, void *d_workspace, size_t workspace_bytes,
+                        void *stream)
+{
+    if (!out) return fail(CRENDER_EINVAL, "crender_plan_create: null out");
+    *out = nullptr;
+    Layout L;
+    if (!make_layout(H, W, y0, y1, max_T, bin_capacity, tile, L))
+        return fail(CRENDER_EINVAL, "crender_plan_create: bad geometry (need 0 <= y0 < y1 <= H, "
+                                    "H, W <= 65535, max_T >= 0)");
+    if (!d_workspace) return fail(CRENDER_EINVAL, "crender_plan_create: null workspace");
+    if (((uintptr_t)d_workspace & (kAlign - 1)) != 0)
+        return fail(CRENDER_EINVAL, "crender_plan_create: workspace must be 256-byte aligned");
+    if (workspace_bytes < L.total) return fail(CRENDER_ENOMEM, "crender_plan_create: workspace too small");
+    crender_plan *p = new (std::nothrow) crender_plan();
+    if (!p) return fail(CRENDER_ENOMEM, "crender_plan_create: host allocation failed");
+    p->L = L;
+    p->ws = static_cast<unsigned char *>(d_workspace);
+    // header + per-tile counters start at zero; the frame kernels keep them zero
+    hipError_t e = hipMemsetAsync(p->ws, 0, L.off_offs, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        delete p;
+        return fail_hip(e, "hipMemsetAsync(workspace)");
+    }
+    *out = p;
+    return CRENDER_OK;
+}
+
+void crender_plan_destroy(crender_plan *plan)
+{
+    if (!plan) return;
+    for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
+    delete plan;
+}
+
+int crender_plan_timing_begin(crender_plan *plan, int max_frames)
+{
+    if (!plan || max_frames < 0) return fail(CRENDER_EINVAL, "crender_plan_timing_begin: bad argument");
+    for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
+    plan->events.clear();
+    plan->timed_frames = 0;
+    plan->events.reserve((size_t)max_frames * 3);
+    for (int i = 0; i < max_frames * 3; ++i) {
+        hipEvent_t e;
+        CR_HIP(hipEventCreate(&e));
+        plan->events.push_back(e);
+    }
+    return CRENDER_OK;
+}
+
+int crender_plan_timing_end(crender_plan *plan, void *stream, int *frames, double *bin_ms_avg,
+                            double *raster_ms_avg)
+{
+    if (!plan) return fail(CRENDER_EINVAL, "null plan");
+    CR_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    double bin = 0.0, ras = 0.0;
+    const int n = plan->timed_frames;
+    for (int f = 0; f < n; ++f) {
+        float a = 0.f, b = 0.f;
+        CR_HIP(hipEventElapsedTime(&a, plan->events[(size_t)f * 3], plan->events[(size_t)f * 3 + 1]));
+        CR_HIP(hipEventElapsedTime(&b, plan->events[(size_t)f * 3 + 1], plan->events[(size_t)f * 3 + 2]));
+        bin += a;
+        ras += b;
+    }
+    if (frames) *frames = n;
+    if (bin_ms_avg) *bin_ms_avg = n ? bin / n : 0.0;
+    if (raster_ms_avg) *raster_ms_avg = n ? ras / n : 0.0;
+    for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
+    plan->events.clear();
+    plan->timed_frames = 0;
+    return CRENDER_OK;
+}
+
+int crender_plan_last_bin_usage(crender_plan *plan, void *stream, int64_t *needed, int64_t *capacity)
+{
+    if (!plan) return fail(CRENDER_EINVAL, "null plan");
+    uint32_t h = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    CR_HIP(hipMemcpyAsync(&h, plan->hdr(), sizeof h, hipMemcpyDeviceToHost, s));
+    CR_HIP(hipStreamSynchronize(s));
+    if (needed) *needed = h;
+    if (capacity) *capacity = plan->L.capacity;
+    return CRENDER_OK;
+}
+
+int crender_raster(crender_plan *plan, const float *d_tri_proj, const float *d_col, const float *d_nrm,
+                   int64_t T, float *d_z, float *d_color, float *d_normal, int32_t *d_winner,
+                   unsigned flags, void *stream)
+{
+    return tile_frame(plan, false, d_tri_proj, d_col, d_nrm, T, nullptr, d_z, d_color, d_normal,
+                      d_winner, flags, stream);
+}
+
+int crender_render_model(crender_plan *plan, const float *d_tri, const float *d_col, const float *d_nrm,
+                         int64_t T, const float *P16, float *d_z, float *d_color, float *d_normal,
+                         int32_t *d_winner, unsigned flags, void *stream)
+{
+    return tile_frame(plan, true, d_tri, d_col, d_nrm, T, P16, d_z, d_color, d_normal, d_winner, flags,
+                      stream);
+}
+
+size_t crender_atomic_scratch_bytes(int H, int W)
+{
+    if (H <= 0 || W <= 0) return 0;
+    return sizeof(unsigned long long) * (size_t)H * (size_t)W;
+}
+
+int crender_raster_atomic(const float *d_tri_proj, const float *d_col, const float *d_nrm, int64_t T,
+                          float *d_z, float *d_color, float *d_normal, int32_t *d_winner, int H, int W,
+                          int y0, int y1, unsigned flags, void *d_keys, void *stream)
+{
+    if (!d_z || !d_color || !d_normal || !d_keys || H <= 0 || W <= 0 || y0 < 0 || y1 > H || y0 >= y1 ||
+        T < 0 || T > 0xFFFFFFF0ll)
+        return fail(CRENDER_EINVAL, "crender_raster_atomic: bad argument");
+    if (T > 0 && (!d_tri_proj || !d_col || !d_nrm))
+        return fail(CRENDER_EINVAL, "crender_raster_atomic: null triangle array");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t first = (size_t)y0 * W, npix = (size_t)(y1 - y0) * W;
+    const int clear = (flags & CRENDER_FUSED_CLEAR) ? 1 : 0;
+    unsigned long long *keys = static_cast<unsigned long long *>(d_keys);
+    hipLaunchKernelGGL(k_keys_init, dim3(grid_for(npix, 4096)), dim3(kThreads), 0, s, keys, d_z, first,
+                       npix, clear);
+    CR_LAUNCH_CHECK("k_keys_init");
+    if (T > 0) {
+        hipLaunchKernelGGL(k_cover_atomic, dim3(grid_for((size_t)T * 64, 8192)), dim3(kThreads), 0, s,
+                           d_tri_proj, d_nrm, keys, T, W, H, y0, y1);
+        CR_LAUNCH_CHECK("k_cover_atomic");
+    }
+    hipLaunchKernelGGL(k_resolve_global, dim3(grid_for(npix, 8192)), dim3(kThreads), 0, s, d_tri_proj,
+                       d_col, d_nrm, keys, d_z, d_color, d_normal, d_winner, W, first, npix, clear);
+    CR_LAUNCH_CHECK("k_resolve_global");
+    return CRENDER_OK;
+}
+
+int crender_guro_illumination(float *d_color, const float *d_normal, const float *light3, int H, int W,
+                              int y0, int y1, void *stream)
+{
+    if (!d_color || !d_normal || !light3 || H <= 0 || W <= 0 || y0 < 0 || y1 > H || y0 >= y1)
+        return fail(CRENDER_EINVAL, "crender_guro_illumination: bad argument");
+    const size_t first = (size_t)y0 * W, npix = (size_t)(y1 - y0) * W;
+    hipLaunchKernelGGL(k_guro, dim3(grid_for(npix, 4096)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), d_color, d_normal, light3[0], light3[1],
+                       light3[2], first, npix);
+    CR_LAUNCH_CHECK("k_guro");
+    return CRENDER_OK;
+}
+
+}  // extern "C"

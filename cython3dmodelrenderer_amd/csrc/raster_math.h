@@ -1,0 +1,197 @@
+// raster_math.h — per-vertex / per-sample arithmetic of the rasterizer (device side).
+//
+// Every function states the reference lines whose float32 operation order it keeps
+// (".pyx" = crender/cy/pixel_buffer_filler/advanced_pixel_buffer_filler.pyx,
+//  "mu.pyx" = crender/cy/pixel_buffer_filler/math_utils.pyx of the reference).
+// The translation unit MUST be built with -ffp-contract=off, correctly rounded f32
+// division and f32 denormals enabled: each operator below is one IEEE binary32
+// operation, exactly as in the reference's gcc -O2 x86-64 build.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CR_DEV __device__ __forceinline__
+
+namespace crender {
+
+// Projection constants handed to kernels by value (a3, .pyx:83-90 and .pyx:109).
+struct ProjConst {
+    float p[16];   // row-major 4x4
+    float xs, ys;  // (float)(w / 2.0), (float)(h / 2.0)
+};
+
+// K1 body for one vertex, .pyx:116-130.  The reference runs in place, so column j
+// is formed from the already overwritten columns < j; v[] is updated the same way.
+CR_DEV void project_vertex(const ProjConst &P, float v[3])
+{
+    const float z = v[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        v[j] = v[0] * P.p[0 * 4 + j] + v[1] * P.p[1 * 4 + j] + v[2] * P.p[2 * 4 + j] + P.p[3 * 4 + j];
+    v[0] = v[0] / z;
+    v[1] = v[1] / z;
+    v[2] = v[2] / z;
+    v[0] = v[0] + 1.0f;
+    v[1] = v[1] + 1.0f;
+    v[0] = v[0] * P.xs;
+    v[1] = v[1] * P.ys;
+}
+
+// .pyx:202: (n0z + n1z + n2z) / 3 >= 0.0 with a float sum and a DOUBLE division by
+// 3.0 (what Cython emits).  A double quotient of a float by 3 is zero only if the
+// float is, and keeps its sign, so the test equals `sum >= 0` (true for -0, false for
+// NaN) and the division is not needed.
+CR_DEV bool backface(float n0z, float n1z, float n2z)
+{
+    const float s = n0z + n1z + n2z;
+    return s >= 0.0f;
+}
+
+// <int>ceil(x) of the reference's x86-64 build (.pyx:165-166): the double ceil of a
+// float is the float ceil; cvttsd2si returns INT_MIN for anything outside int range.
+CR_DEV int ceil_to_int(float x)
+{
+    const float c = ceilf(x);
+    if (!(c >= -2147483648.0f && c < 2147483648.0f)) return (int)0x80000000;
+    return (int)c;
+}
+
+CR_DEV int clipi(int a, int lo, int hi)  // mu.pxd:8-13
+{
+    return a < lo ? lo : (a > hi ? hi : a);
+}
+
+// a6, .pyx:132-175: pixel box [xl, xr) x [yt, yb) of a projected triangle.
+CR_DEV void pixel_box(float x0, float y0, float x1, float y1, float x2, float y2,
+                      int w, int h, int &xl, int &xr, int &yt, int &yb)
+{
+    float fxl = (float)w, fxr = 0.0f, fyt = (float)h, fyb = 0.0f;
+    if (x0 < fxl) fxl = x0;
+    if (x0 > fxr) fxr = x0;
+    if (y0 < fyt) fyt = y0;
+    if (y0 > fyb) fyb = y0;
+    if (x1 < fxl) fxl = x1;
+    if (x1 > fxr) fxr = x1;
+    if (y1 < fyt) fyt = y1;
+    if (y1 > fyb) fyb = y1;
+    if (x2 < fxl) fxl = x2;
+    if (x2 > fxr) fxr = x2;
+    if (y2 < fyt) fyt = y2;
+    if (y2 > fyb) fyb = y2;
+    xl = clipi(ceil_to_int(fxl), 0, w);
+    xr = clipi(ceil_to_int(fxr), 0, w);
+    yt = clipi(ceil_to_int(fyt), 0, h);
+    yb = clipi(ceil_to_int(fyb), 0, h);
+}
+
+// The six xy coordinates + three depths of a projected triangle.
+struct TriXYZ {
+    float x0, y0, z0, x1, y1, z1, x2, y2, z2;
+};
+
+// a9, mu.pyx:8-34: barycentrics of integer pixel (X, Y).  The nine edge constants are
+// functions of the triangle only; they are written inline so the compiler hoists them
+// out of sample loops.  Three correctly rounded divisions, no reciprocal.
+CR_DEV void barycentric(const TriXYZ &t, int X, int Y, float &b1, float &b2, float &b3)
+{
+    const float l01 = t.x1 - t.x2, l02 = t.y1 - t.y2;
+    const float l03 = l01 * (t.y0 - t.y2) - l02 * (t.x0 - t.x2);
+    const float l11 = t.x2 - t.x0, l12 = t.y2 - t.y0;
+    const float l13 = l11 * (t.y1 - t.y0) - l12 * (t.x1 - t.x0);
+    const float l21 = t.x0 - t.x1, l22 = t.y0 - t.y1;
+    const float l23 = l21 * (t.y2 - t.y1) - l22 * (t.x2 - t.x1);
+    const float fx = (float)X, fy = (float)Y;
+    b1 = (l01 * (fy - t.y2) - l02 * (fx - t.x2)) / l03;
+    b2 = (l11 * (fy - t.y0) - l12 * (fx - t.x0)) / l13;
+    b3 = (l21 * (fy - t.y1) - l22 * (fx - t.x1)) / l23;
+}
+
+// .pyx:219 / 226-231: attribute interpolation, a0*b1 + a1*b2 + a2*b3 left to right.
+CR_DEV float interp(float a0, float a1, float a2, float b1, float b2, float b3)
+{
+    return a0 * b1 + a1 * b2 + a2 * b3;
+}
+
+// ---- depth keys ------------------------------------------------------------------
+// The reference's serial loop leaves, per pixel, the minimum-z fragment, ties to the
+// highest triangle index, a fragment equal to the prior buffer value overwriting it
+// (write on `not new_z > z`, .pyx:223).  That is the minimum of the 64-bit keys
+//     (order-preserving map of z) << 32 | (0xFFFFFFFE - triangle)   for fragments
+//     (order-preserving map of z) << 32 |  0xFFFFFFFF               for the prior value
+// so the whole z-order reduces to an order-independent unsigned 64-bit atomic min.
+constexpr uint32_t KEY_LOW_PRIOR = 0xFFFFFFFFu;
+
+CR_DEV uint32_t zord(float z)  // z is not NaN; -0 and +0 compare equal in the reference
+{
+    if (z == 0.0f) z = 0.0f;
+    const uint32_t u = __float_as_uint(z);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+CR_DEV uint32_t zord_prior(float z)  // prior buffer content: a NaN loses to everything
+{
+    return (z != z) ? 0xFFFFFFFFu : zord(z);
+}
+
+CR_DEV unsigned long long make_key(uint32_t zo, uint32_t low)
+{
+    return ((unsigned long long)zo << 32) | low;
+}
+
+CR_DEV unsigned long long fragment_key(float z, uint32_t tri)
+{
+    return make_key(zord(z), 0xFFFFFFFEu - tri);
+}
+
+// Coverage test of one sample: returns true and the key if pixel (X, Y) yields a
+// fragment (.pyx:215-221: all barycentrics non-negative — NaN passes — and z not NaN).
+CR_DEV bool fragment(const TriXYZ &t, uint32_t tri, int X, int Y, unsigned long long &key)
+{
+    float b1, b2, b3;
+    barycentric(t, X, Y, b1, b2, b3);
+    if (b1 < 0.0f || b2 < 0.0f || b3 < 0.0f) return false;
+    const float z = interp(t.z0, t.z1, t.z2, b1, b2, b3);
+    if (z != z) return false;  // == not (-1 <= z or z <= 1), .pyx:220
+    key = fragment_key(z, tri);
+    return true;
+}
+
+// Load nine consecutive floats (one triangle of a [T][3][3] array).
+CR_DEV void load9(const float *__restrict__ p, float v[9])
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = p[i];
+}
+
+CR_DEV TriXYZ load_tri(const float *__restrict__ p)
+{
+    float v[9];
+    load9(p, v);
+    return TriXYZ{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]};
+}
+
+// Recompute the winning fragment of pixel (X, Y) and store z, colour, normal
+// (.pyx:219, 226-242).  Same device functions as the coverage pass, so z is the very
+// value the key was built from.
+CR_DEV void shade_and_store(const float *__restrict__ proj, const float *__restrict__ col,
+                            const float *__restrict__ nrm, uint32_t tri, int X, int Y,
+                            size_t pix, float *__restrict__ zb, float *__restrict__ cb,
+                            float *__restrict__ nb)
+{
+    const TriXYZ t = load_tri(proj + (size_t)tri * 9);
+    float c[9], n[9];
+    load9(col + (size_t)tri * 9, c);
+    load9(nrm + (size_t)tri * 9, n);
+    float b1, b2, b3;
+    barycentric(t, X, Y, b1, b2, b3);
+    zb[pix] = interp(t.z0, t.z1, t.z2, b1, b2, b3);
+    float *cp = cb + pix * 3, *np_ = nb + pix * 3;
+    cp[0] = interp(c[0], c[3], c[6], b1, b2, b3);
+    cp[1] = interp(c[1], c[4], c[7], b1, b2, b3);
+    cp[2] = interp(c[2], c[5], c[8], b1, b2, b3);
+    np_[0] = interp(n[0], n[3], n[6], b1, b2, b3);
+    np_[1] = interp(n[1], n[4], n[7], b1, b2, b3);
+    np_[2] = interp(n[2], n[5], n[8], b1, b2, b3);
+}
+
+}  // namespace crender

@@ -1,0 +1,1 @@
+from .model import Model  # noqa: F401

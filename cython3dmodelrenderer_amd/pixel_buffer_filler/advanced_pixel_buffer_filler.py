@@ -1,0 +1,285 @@
+"""MI355X drop-in for the reference's Version-C ``AdvancedPixelBufferFiller``.
+
+Mirrors, name for name, the class at
+crender/cy/pixel_buffer_filler/advanced_pixel_buffer_filler.pyx:20-253 of the reference:
+
+    AdvancedPixelBufferFiller(h, w, fov=90.0, z_near=0.1, z_far=1000.0, n_threads=1)
+    .get_size()  .render_model(model)
+    .get_normals_buffer()  .get_color_buffer()  .get_z_buffer()
+
+The framebuffers and the model arrays live in HBM as torch-ROCm tensors; every call
+goes through the C ABI of libcrender_hip.so (include/crender_hip.h).  torch supplies
+device memory and the HIP stream only.  There is no CPU path: without the HIP library
+or a GPU the constructor raises.
+
+Behaviour kept from the reference
+  * buffers persist across ``render_model`` calls and are never cleared, so successive
+    renders composite (``Renderer.reset_buffers`` is a no-op there, renderer.py:51-52);
+  * getters hand out writable numpy arrays that stay valid and that callers may change
+    in place (GuroIllumination does, guro_illumination.py:27); such changes are carried
+    back to the device before the next render;
+  * ``model._colors_by_triangles is None`` raises AttributeError, float64 arrays raise
+    ValueError (.pyx:94-96 binds ``float[:, :, :]`` after ``.copy()``);
+  * ``n_threads`` is accepted and ignored.
+Not kept: the debug printf lines (.pyx:112,197) and the swallowed ZeroDivisionError for
+a vertex with z == 0 (out of contract; IEEE inf/NaN semantics apply instead).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _capi
+
+
+def _as_device_f32(a, name, device):
+    """[T, 3, 3] float32 contiguous tensor on `device` from numpy / torch input."""
+    if a is None:
+        # what `None.copy()` raises in the reference (.pyx:94-96)
+        raise AttributeError("'NoneType' object has no attribute 'copy'")
+    if isinstance(a, torch.Tensor):
+        if a.dtype != torch.float32:
+            raise ValueError(f"Buffer dtype mismatch, expected 'float' but got '{a.dtype}' ({name})")
+        t = a.to(device=device).contiguous()
+    else:
+        arr = np.asarray(a)
+        if arr.dtype != np.float32:
+            kind = "double" if arr.dtype == np.float64 else str(arr.dtype)
+            raise ValueError(f"Buffer dtype mismatch, expected 'float' but got '{kind}'")
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+    if t.dim() != 3 or t.shape[1] != 3 or t.shape[2] != 3:
+        raise ValueError(f"{name} must have shape [T, 3, 3], got {tuple(t.shape)}")
+    return t
+
+
+class AdvancedPixelBufferFiller:
+    def __init__(self, h, w, fov=90.0, z_near=0.1, z_far=1000.0, n_threads=1, *,
+                 device=None, tile=0, row_strip=None, track_winner=False, cache_inputs=True,
+                 bin_capacity=0):
+        self._lib = _capi.load()                      # raises if the HIP library is missing
+        if not torch.cuda.is_available():
+            raise _capi.CrenderError("AdvancedPixelBufferFiller needs a ROCm GPU (no CPU fallback)")
+        self.h, self.w = int(h), int(w)
+        self.fov, self.z_near, self.z_far = float(fov), float(z_near), float(z_far)
+        self.n_threads = n_threads                    # accepted for API parity, unused
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.tile = int(tile)
+        self.y0, self.y1 = (0, self.h) if row_strip is None else (int(row_strip[0]), int(row_strip[1]))
+        self.cache_inputs = cache_inputs
+        self._bin_request = int(bin_capacity)   # 0 = let the library size the bin lists
+
+        P = (C.c_float * 16)()
+        _capi.check(self._lib.crender_projection_matrix(self.fov, self.z_near, self.z_far,
+                                                        self.h, self.w, P), "crender_projection_matrix")
+        self._P = P
+        self.proj_mat = np.array(P[:], dtype=np.float32).reshape(4, 4)
+
+        with torch.cuda.device(self.device):
+            # same initial state as __cinit__ (.pyx:65-67)
+            self.z_buffer = torch.full((self.h, self.w), 1e6, dtype=torch.float32, device=self.device)
+            self.color_buffer = torch.zeros((self.h, self.w, 3), dtype=torch.float32, device=self.device)
+            self.normals_buffer = torch.zeros((self.h, self.w, 3), dtype=torch.float32, device=self.device)
+            self.winner_buffer = (torch.full((self.h, self.w), -1, dtype=torch.int32, device=self.device)
+                                  if track_winner else None)
+        self._plan = C.c_void_p()
+        self._plan_max_T = -1
+        self._plan_capacity = 0
+        self._workspace = None
+        self._inputs = None            # (tri, col, nrm) device tensors of the last frame
+        self._input_key = None
+        self._last_flags = 0
+        self._host = {}                # name -> numpy mirror handed out by a getter
+        self._host_fresh = False       # mirrors equal the device buffers
+        self._host_exposed = False     # a mirror was handed out and may have been edited
+
+    # ------------------------------------------------------------------ plumbing --
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None):
+                self._lib.crender_plan_destroy(self._plan)
+                self._plan = C.c_void_p()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ensure_plan(self, T, capacity=None):
+        capacity = self._bin_request if capacity is None else capacity
+        if self._plan and T <= self._plan_max_T and capacity <= self._plan_capacity:
+            return
+        if self._plan:
+            torch.cuda.current_stream(self.device).synchronize()
+            self._lib.crender_plan_destroy(self._plan)
+            self._plan = C.c_void_p()
+        max_T = max(int(T), 1)
+        nbytes = self._lib.crender_plan_workspace_bytes(self.h, self.w, self.y0, self.y1, max_T,
+                                                        int(capacity), self.tile)
+        if nbytes == 0:
+            raise _capi.CrenderError("bad frame geometry for the tile rasterizer: "
+                                     f"h={self.h} w={self.w} strip=({self.y0},{self.y1})")
+        self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        plan = C.c_void_p()
+        _capi.check(self._lib.crender_plan_create(C.byref(plan), self.h, self.w, self.y0, self.y1,
+                                                  max_T, int(capacity), self.tile,
+                                                  self._workspace.data_ptr(), nbytes, self._stream()),
+                    "crender_plan_create")
+        self._plan = plan
+        self._plan_max_T = max_T
+        need, cap = C.c_int64(), C.c_int64()
+        _capi.check(self._lib.crender_plan_last_bin_usage(plan, self._stream(), C.byref(need),
+                                                          C.byref(cap)), "crender_plan_last_bin_usage")
+        self._plan_capacity = cap.value
+
+    def _push_host_edits(self):
+        """Carry in-place edits of handed-out numpy views back to the device."""
+        if not self._host_exposed:
+            return
+        for name, buf in (("z", self.z_buffer), ("color", self.color_buffer),
+                          ("normals", self.normals_buffer)):
+            if name in self._host:
+                buf.copy_(torch.from_numpy(self._host[name]), non_blocking=False)
+        self._host_exposed = False
+
+    def _win_ptr(self):
+        return self.winner_buffer.data_ptr() if self.winner_buffer is not None else None
+
+    def _launch(self, flags):
+        tri, col, nrm = self._inputs
+        T = tri.shape[0]
+        self._ensure_plan(T)
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.crender_render_model(
+                self._plan, tri.data_ptr(), col.data_ptr(), nrm.data_ptr(), T, self._P,
+                self.z_buffer.data_ptr(), self.color_buffer.data_ptr(), self.normals_buffer.data_ptr(),
+                self._win_ptr(), flags, self._stream()), "crender_render_model")
+        self._last_flags = flags
+        self._host_fresh = False
+
+    def _check_bins(self):
+        """Synchronise; if the last frame overflowed its bin lists, grow them and redo it.
+        Re-rendering is exact: the result is a per-pixel minimum over the prior value and
+        all fragments, so fragments that already landed change nothing."""
+        if not self._plan or self._inputs is None:
+            torch.cuda.current_stream(self.device).synchronize()
+            return
+        need, cap = C.c_int64(), C.c_int64()
+        _capi.check(self._lib.crender_plan_last_bin_usage(self._plan, self._stream(), C.byref(need),
+                                                          C.byref(cap)), "crender_plan_last_bin_usage")
+        if need.value > cap.value:
+            self._ensure_plan(self._inputs[0].shape[0], capacity=int(need.value * 1.25) + 1024)
+            self._launch(self._last_flags)
+            self._check_bins()
+
+    # ------------------------------------------------------------- reference API --
+    def get_size(self):
+        return self.h, self.w
+
+    def render_model(self, model, refresh=False):
+        """Project and rasterize ``model`` on top of the current buffers (.pyx:92-104)."""
+        src = (model._vertices_by_triangles, model._colors_by_triangles, model._normals_by_triangles)
+        key = tuple((id(a), getattr(a, "shape", None)) for a in src)
+        if refresh or not self.cache_inputs or key != self._input_key:
+            self._inputs = (_as_device_f32(src[0], "model._vertices_by_triangles", self.device),
+                            _as_device_f32(src[1], "model._colors_by_triangles", self.device),
+                            _as_device_f32(src[2], "model._normals_by_triangles", self.device))
+            if not (self._inputs[0].shape == self._inputs[1].shape == self._inputs[2].shape):
+                raise ValueError("vertex, colour and normal arrays must have the same shape")
+            self._input_key = key
+            self._input_refs = src         # keep ids alive while the key is cached
+        self._push_host_edits()
+        self._launch(0)
+
+    # north_star wording; the reference's method is render_model
+    render = render_model
+
+    def get_normals_buffer(self):
+        return self._mirror("normals", self.normals_buffer)
+
+    def get_color_buffer(self):
+        return self._mirror("color", self.color_buffer)
+
+    def get_z_buffer(self):
+        return self._mirror("z", self.z_buffer)
+
+    # ------------------------------------------------------------------ extensions --
+    def render_arrays(self, tri, col, nrm, clear=False):
+        """``render_model`` on explicit [T,3,3] float32 arrays (numpy or torch, any device).
+        ``clear=True`` renders into freshly initialised buffers in the same pass."""
+        self._inputs = (_as_device_f32(tri, "tri", self.device), _as_device_f32(col, "col", self.device),
+                        _as_device_f32(nrm, "nrm", self.device))
+        self._input_key = None
+        if clear:
+            self._host_exposed = False
+        else:
+            self._push_host_edits()
+        self._launch(_capi.FUSED_CLEAR if clear else 0)
+
+    def render_frame(self):
+        """One benchmark frame: clear + project + rasterize the resident model
+        (SURVEY.md section 8d 'one frame').  Inputs must have been set by a previous
+        render_model / render_arrays call."""
+        self._launch(_capi.FUSED_CLEAR)
+
+    def clear(self):
+        """Back to the state __cinit__ leaves (.pyx:65-67)."""
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.crender_clear(self.z_buffer.data_ptr(), self.color_buffer.data_ptr(),
+                                                self.normals_buffer.data_ptr(), self._win_ptr(),
+                                                self.h, self.w, self.y0, self.y1, self._stream()),
+                        "crender_clear")
+        self._host_fresh = False
+        self._host_exposed = False
+
+    def synchronize(self):
+        self._check_bins()
+
+    def bin_usage(self):
+        need, cap = C.c_int64(), C.c_int64()
+        _capi.check(self._lib.crender_plan_last_bin_usage(self._plan, self._stream(), C.byref(need),
+                                                          C.byref(cap)), "crender_plan_last_bin_usage")
+        return need.value, cap.value
+
+    def timing_begin(self, max_frames):
+        """Record HIP events around the binning passes and the raster kernel of the next
+        `max_frames` frames (measurement aid used by bench.py)."""
+        _capi.check(self._lib.crender_plan_timing_begin(self._plan, int(max_frames)),
+                    "crender_plan_timing_begin")
+
+    def timing_end(self):
+        """-> (frames, average ms of the binning passes, average ms of the raster kernel)."""
+        n, b, r = C.c_int(), C.c_double(), C.c_double()
+        _capi.check(self._lib.crender_plan_timing_end(self._plan, self._stream(), C.byref(n),
+                                                      C.byref(b), C.byref(r)), "crender_plan_timing_end")
+        return n.value, b.value, r.value
+
+    def get_z_tensor(self):
+        self._check_bins()
+        return self.z_buffer
+
+    def get_color_tensor(self):
+        self._check_bins()
+        return self.color_buffer
+
+    def get_normals_tensor(self):
+        self._check_bins()
+        return self.normals_buffer
+
+    def get_winner_tensor(self):
+        self._check_bins()
+        return self.winner_buffer
+
+    def _mirror(self, name, buf):
+        if not self._host_fresh:
+            self._check_bins()
+            for n, b in (("z", self.z_buffer), ("color", self.color_buffer),
+                         ("normals", self.normals_buffer)):
+                if n in self._host:
+                    self._host[n][...] = b.cpu().numpy()
+            self._host_fresh = True
+        if name not in self._host:
+            self._host[name] = buf.cpu().numpy()
+        self._host_exposed = True
+        return self._host[name]

@@ -1,0 +1,144 @@
+/*
+ * crender_hip.h — C ABI of the MI355X (gfx950) rasterizer.
+ *
+ * Drop-in boundary for ONE path of oKatanaaa/Cython3DModelRenderer: the Version-C
+ * filler `AdvancedPixelBufferFiller.render_model(model)`.  Reference file cited
+ * below as ".pyx" = crender/cy/pixel_buffer_filler/advanced_pixel_buffer_filler.pyx,
+ * "mu.pyx" = crender/cy/pixel_buffer_filler/math_utils.pyx.
+ *
+ * Conventions
+ *   - plain C: raw pointers, sizes, an opaque plan handle; no torch / C++ types.
+ *   - every `d_*` pointer is DEVICE memory (hipMalloc'ed or a torch-ROCm tensor's
+ *     data_ptr()); `P16` and every other pointer is HOST memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All
+ *     work is enqueued on it; nothing synchronises unless stated.
+ *   - triangle arrays are C-contiguous float32 [T][3][3] (the layout the reference
+ *     binds at .pyx:94-96 after `.copy()`): 9 floats per triangle, 36 bytes.
+ *   - framebuffers are C-contiguous float32: z [H][W], colour [H][W][3] (BGR 0..255),
+ *     normal [H][W][3]  (.pyx:65-67).  They always address the FULL frame; a call only
+ *     touches rows y0 <= y < y1 (row strips for multi-GPU; y0 = 0, y1 = H otherwise).
+ *   - every entry point returns CRENDER_OK (0) or an error code and never throws;
+ *     crender_last_error() gives the text for the calling thread.
+ *
+ * Result contract: after crender_raster / crender_render_model the buffers hold, bit
+ * for bit, what the reference's 1-thread loop leaves:
+ * per pixel the fragment with the smallest z among all fragments and the prior buffer
+ * value; equal z -> the highest triangle index; a fragment equal to the prior value
+ * overwrites it.
+ */
+#ifndef CRENDER_HIP_H
+#define CRENDER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRENDER_ABI_VERSION 1
+#define CRENDER_API __attribute__((visibility("default")))
+
+enum {
+    CRENDER_OK = 0,
+    CRENDER_EINVAL = 1,  /* bad argument (null pointer, negative size, bad strip) */
+    CRENDER_EHIP = 2,    /* HIP runtime error; text in crender_last_error()       */
+    CRENDER_ENOMEM = 3   /* workspace smaller than crender_plan_workspace_bytes   */
+};
+
+/* flags of crender_raster / crender_render_model / crender_raster_atomic */
+enum {
+    /* Treat the strip as freshly initialised (z = 1e6, colour = normal = 0, the state
+     * __cinit__ leaves, .pyx:65-67) instead of reading it, and write every pixel of
+     * the strip exactly once.  Equivalent to crender_clear followed by a flag-less
+     * call, without the extra pass over the framebuffer. */
+    CRENDER_FUSED_CLEAR = 1u
+};
+
+CRENDER_API int crender_abi_version(void);
+CRENDER_API const char *crender_last_error(void);
+
+/* replaces: __cinit__ scalars + _init_projection_matrix (.pyx:54-59, 83-90).
+ * Writes the row-major float32 4x4 matrix P = [[f/a,0,0,0],[0,f,0,0],[0,0,q,1],
+ * [0,0,-z_near*q,0]] with the reference's float32 rounding steps. */
+CRENDER_API int crender_projection_matrix(double fov_deg, double z_near, double z_far,
+                              int h, int w, float *P16);
+
+/* replaces: project_on_screen_multithread (K1, .pyx:106-130).
+ * d_tri_out may equal d_tri_in (the reference always projects in place, .pyx:99). */
+CRENDER_API int crender_project(const float *d_tri_in, float *d_tri_out, int64_t T,
+                    const float *P16, int w, int h, void *stream);
+
+/* replaces: the buffer initialisation of __cinit__ (.pyx:65-67) for rows [y0, y1).
+ * d_winner (int32 [H][W], optional) is set to -1. */
+CRENDER_API int crender_clear(float *d_z, float *d_color, float *d_normal, int32_t *d_winner,
+                  int H, int W, int y0, int y1, void *stream);
+
+/* ---- plan: frame geometry + carve-up of a caller-owned device workspace ----------
+ * The tile rasterizer bins triangles into screen tiles; a plan fixes the strip, the
+ * tile size and the capacity of the bin lists inside `d_workspace`.  The workspace
+ * must stay allocated and untouched by others for the plan's lifetime. */
+typedef struct crender_plan crender_plan;
+
+/* tile: 0 = automatic, 32 or 64.  bin_capacity: number of (tile, triangle) list
+ * entries to reserve; 0 = automatic (4 per triangle + slack). */
+CRENDER_API size_t crender_plan_workspace_bytes(int H, int W, int y0, int y1, int64_t max_T,
+                                    int64_t bin_capacity, int tile);
+CRENDER_API int crender_plan_create(crender_plan **out, int H, int W, int y0, int y1,
+                        int64_t max_T, int64_t bin_capacity, int tile,
+                        void *d_workspace, size_t workspace_bytes, void *stream);
+CRENDER_API void crender_plan_destroy(crender_plan *plan);
+
+/* Synchronises `stream`, then reports the number of bin-list entries the most recent
+ * crender_raster / crender_render_model on this plan needed and the capacity it had.
+ * needed > capacity means that frame dropped fragments: recreate the plan with
+ * bin_capacity >= needed and render again. */
+CRENDER_API int crender_plan_last_bin_usage(crender_plan *plan, void *stream,
+                                int64_t *needed, int64_t *capacity);
+
+/* Measurement aid (no reference counterpart): record HIP events on the frame's own
+ * stream around the binning passes and around the raster kernel of each of the next
+ * `max_frames` frames; crender_plan_timing_end synchronises and returns the averages. */
+CRENDER_API int crender_plan_timing_begin(crender_plan *plan, int max_frames);
+CRENDER_API int crender_plan_timing_end(crender_plan *plan, void *stream, int *frames,
+                            double *bin_ms_avg, double *raster_ms_avg);
+
+/* replaces: compute_triangle_statistics_multithread (K2, .pyx:177-244) including
+ * _compute_pixel_coords_c (.pyx:132-175) and compute_bar_coords_single_pixel
+ * (mu.pyx:8-34).  d_tri_proj holds K1's output.  d_winner (optional, int32 [H][W])
+ * receives the index of the triangle whose fragment each written pixel holds.
+ * Tile-binned LDS rasterizer (the production path). */
+CRENDER_API int crender_raster(crender_plan *plan, const float *d_tri_proj, const float *d_col,
+                   const float *d_nrm, int64_t T,
+                   float *d_z, float *d_color, float *d_normal, int32_t *d_winner,
+                   unsigned flags, void *stream);
+
+/* replaces: render_model (.pyx:92-104) = K1 into the plan's scratch + K2, with the
+ * projection fused into the binning pass.  d_tri is the UNPROJECTED vertex array and
+ * is not modified. */
+CRENDER_API int crender_render_model(crender_plan *plan, const float *d_tri, const float *d_col,
+                         const float *d_nrm, int64_t T, const float *P16,
+                         float *d_z, float *d_color, float *d_normal, int32_t *d_winner,
+                         unsigned flags, void *stream);
+
+/* Same contract as crender_raster, computed a second, independent way: one wavefront
+ * per triangle, 64-bit global atomics on a packed (z, index) key plane, then a
+ * per-pixel resolve.  Needs no plan; d_keys is caller-owned scratch of
+ * crender_atomic_scratch_bytes(H, W) bytes.  Used to cross-check the tile path at
+ * sizes where the CPU oracle is slow. */
+CRENDER_API size_t crender_atomic_scratch_bytes(int H, int W);
+CRENDER_API int crender_raster_atomic(const float *d_tri_proj, const float *d_col, const float *d_nrm,
+                          int64_t T, float *d_z, float *d_color, float *d_normal,
+                          int32_t *d_winner, int H, int W, int y0, int y1,
+                          unsigned flags, void *d_keys, void *stream);
+
+/* next row f1: GuroIllumination.draw_illumination
+ * (crender/cy/illumination/guro_illumination.py:20-27) on device, in place on the
+ * colour buffer: colour *= clip(n.l / (|n| + 1e-6), 0, 1), rows [y0, y1). */
+CRENDER_API int crender_guro_illumination(float *d_color, const float *d_normal, const float *light3,
+                              int H, int W, int y0, int y1, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRENDER_HIP_H */
