@@ -80,6 +80,8 @@ def main():
                     choices=["cube256", "trex1024", "bunny4096", "trex8192", "synth10m"])
     ap.add_argument("--synth-triangles", type=int, default=10_000_000)
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--max-triangles", type=int, default=-1,
+                    help="experiment knob: keep only the first N triangles (0 = pure clear)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
     args = ap.parse_args()
@@ -105,6 +107,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     tri, col, nrm, (H, W), fov = scenes.scene(args.workload, synth_T=args.synth_triangles)
+    if args.max_triangles >= 0:
+        tri, col, nrm = tri[:args.max_triangles], col[:args.max_triangles], nrm[:args.max_triangles]
     T = int(tri.shape[0])
     y0, y1 = D.strip_rows(H, world, rank)
     filler = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile,

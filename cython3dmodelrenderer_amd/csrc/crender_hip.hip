@@ -21,6 +21,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -171,15 +172,27 @@ CR_DEV uint2 tile_range(const TriXYZ &t, const Geom &G)
     return make_uint2(tx0 | (tx1 << 16), ty0 | (ty1 << 16));
 }
 
-// dynamic LDS: [hist: ntiles u32 if LDS_HIST][verts: 256*9 f32][normals: 256*9 f32]
-template <int TS, bool PROJECT, bool LDS_HIST>
+// Binning mode of k_setup:
+//   kBinCountLds / kBinCountGlobal  count list lengths (LDS histogram or global atomics) and
+//                                   store each triangle's tile range for k_fill (scan path);
+//   kBinDirect                      small scenes: append the triangle index straight into
+//                                   fixed-capacity per-tile lists, no k_scan / k_fill.
+enum { kBinCountLds = 0, kBinCountGlobal = 1, kBinDirect = 2 };
+constexpr int kDirectMaxTilesPerTriangle = 64;  // beyond this the scan path is used instead
+
+// dynamic LDS: [hist: ntiles u32 if kBinCountLds][verts: 256*9 f32][normals: 256*9 f32]
+template <int TS, bool PROJECT, int BIN>
 __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tri_in,
                                                     const float *__restrict__ nrm,
                                                     float *__restrict__ proj_out,
                                                     uint2 *__restrict__ trange,
-                                                    uint32_t *__restrict__ count, int64_t T,
+                                                    uint32_t *__restrict__ count,
+                                                    uint32_t *__restrict__ dlist, uint32_t dcap,
+                                                    uint32_t *__restrict__ hdr, int64_t T,
                                                     int64_t chunk, ProjConst P, Geom G)
 {
+    // the LDS histogram doubles as the block's list cursors in direct mode
+    constexpr bool LDS_HIST = BIN == kBinCountLds || BIN == kBinDirect;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int hist_words = LDS_HIST ? ((G.ntiles + 3) & ~3) : 0;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw);
@@ -197,6 +210,7 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
         stage_in(tri_in + b0 * 9, sv, n * 9);
         stage_in(nrm + b0 * 9, sn, n * 9);
         __syncthreads();
+        uint2 r_keep = make_uint2(kNoTiles, 0);
         if ((int)threadIdx.x < n) {
             float *v = sv + threadIdx.x * 9;
             const float *nn = sn + threadIdx.x * 9;
@@ -214,24 +228,57 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
                 const TriXYZ t{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]};
                 r = tile_range<TS>(t, G);
             }
-            trange[b0 + threadIdx.x] = r;
+            if (BIN != kBinDirect) trange[b0 + threadIdx.x] = r;
             if (r.x != kNoTiles) {
+                const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
+                if (BIN == kBinDirect) {
+                    // pass A of the direct bins: count this block's entries per tile in LDS
+                    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kDirectMaxTilesPerTriangle) {
+                        atomicMax(&hdr[1], 0xFFFFFFFFu);  // sticky: this scene needs the scan path
+                        r.x = kNoTiles;
+                    } else {
+                        for (int ty = ty0; ty <= ty1; ++ty)
+                            for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&hist[ty * G.ntx + tx], 1u);
+                    }
+                } else {
+                    for (int ty = ty0; ty <= ty1; ++ty)
+                        for (int tx = tx0; tx <= tx1; ++tx) {
+                            if (LDS_HIST) atomicAdd(&hist[ty * G.ntx + tx], 1u);
+                            else atomicAdd(&count[ty * G.ntx + tx], 1u);
+                        }
+                }
+            }
+            r_keep = r;
+        }
+        __syncthreads();
+        if (PROJECT) stage_out(proj_out + b0 * 9, sv, n * 9);
+        if (BIN == kBinDirect) {
+            // pass B: one global atomic per touched tile reserves a run of that tile's list;
+            // pass C: the block's entries take consecutive slots of the run (LDS cursors)
+            for (int i = threadIdx.x; i < G.ntiles; i += kThreads) {
+                const uint32_t c = hist[i];
+                if (c) hist[i] = atomicAdd(&count[i], c);
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < n && r_keep.x != kNoTiles) {
+                const uint2 r = r_keep;
+                const uint32_t id = (uint32_t)(b0 + threadIdx.x);
                 const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
                 for (int ty = ty0; ty <= ty1; ++ty)
                     for (int tx = tx0; tx <= tx1; ++tx) {
-                        if (LDS_HIST) atomicAdd(&hist[ty * G.ntx + tx], 1u);
-                        else atomicAdd(&count[ty * G.ntx + tx], 1u);
+                        const int tile = ty * G.ntx + tx;
+                        const uint32_t slot = atomicAdd(&hist[tile], 1u);
+                        if (slot < dcap) dlist[(size_t)tile * dcap + slot] = id;
+                        else atomicMax(&hdr[1], slot + 1);
                     }
             }
-        }
-        __syncthreads();
-        if (PROJECT) {
-            stage_out(proj_out + b0 * 9, sv, n * 9);
             __syncthreads();
+            // cursors back to zero for the block's next batch
+            for (int i = threadIdx.x; i < G.ntiles; i += kThreads) hist[i] = 0;
         }
-    }
-    if (LDS_HIST) {
         __syncthreads();
+    }
+    if (BIN == kBinCountLds) {
         for (int i = threadIdx.x; i < G.ntiles; i += kThreads) {
             const uint32_t c = hist[i];
             if (c) atomicAdd(&count[i], c);
@@ -321,19 +368,10 @@ __global__ __launch_bounds__(kThreads) void k_fill(const uint2 *__restrict__ tra
 }
 
 // ---- tile rasterizer --------------------------------------------------------------
-// Work record of one (tile, triangle) pair, struct-of-arrays in LDS.
-struct WorkQueue {
-    float x0[kThreads], y0[kThreads], z0[kThreads];
-    float x1[kThreads], y1[kThreads], z1[kThreads];
-    float x2[kThreads], y2[kThreads], z2[kThreads];
-    uint32_t tri[kThreads];
-    uint32_t box_xy[kThreads];  // bx0 | by0 << 16  (frame pixel coordinates)
-    uint32_t box_wh[kThreads];  // bw  | bh  << 16
-};
-
-// XCD-aware block -> tile map: workgroups are dealt round-robin over the 8 XCDs, so
-// block b and b + 8 share an L2.  Give each XCD one contiguous band of tiles so that
-// neighbouring tiles, which share triangles, hit the same L2.  Speed only.
+// Alternative block -> tile map (debug knob 8): one contiguous band of tiles per XCD.
+// Measured SLOWER than the identity map on every workload (r01: T-Rex 8192^2 0.60 vs 0.42 ms):
+// the covered tiles cluster, so banding piles the work onto a few XCDs.  The identity map
+// deals neighbouring tiles round-robin over the XCDs and is the default.
 CR_DEV int xcd_band_tile(int b, int n)
 {
     const int per = n >> 3, rem = n & 7;
@@ -348,6 +386,63 @@ CR_DEV void lds_key_min(unsigned long long *slot, unsigned long long k)
     if (k < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMin(slot, k);
 }
 
+// One batch of (tile, triangle) work in LDS, struct-of-arrays, slot = thread index.
+// A record's pixel box (clipped to the tile) is cut into 4x4-pixel blocks, numbered
+// row-major; blk_scan holds the wave-local exclusive prefix of the block counts.
+struct WorkQueue {
+    float x0[kThreads], y0[kThreads], z0[kThreads];
+    float x1[kThreads], y1[kThreads], z1[kThreads];
+    float x2[kThreads], y2[kThreads], z2[kThreads];
+    uint32_t tri[kThreads];
+    uint32_t box_xy[kThreads];    // bx0 | by0 << 16  (frame pixel coordinates)
+    uint32_t box_wh[kThreads];    // bw  | bh  << 16  (0 = no work)
+    uint32_t blk_scan[kThreads];  // exclusive prefix of block counts within the wavefront
+    uint32_t wave_blocks[kThreads / 64];
+};
+
+// The record a 16-lane group is sweeping.
+struct Work {
+    TriXYZ t;
+    uint32_t id;
+    int bx0, by0, bx1, by1;  // clipped pixel box [bx0, bx1) x [by0, by1)
+    int nbx, nblk;           // 4x4 blocks across, in total
+};
+
+CR_DEV int blocks_of(uint32_t box_wh)
+{
+    const int bw = box_wh & 0xFFFF, bh = box_wh >> 16;
+    return ((bw + 3) >> 2) * ((bh + 3) >> 2);
+}
+
+CR_DEV Work load_work(const WorkQueue &q, int r)
+{
+    Work w;
+    w.t = TriXYZ{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r], q.x2[r], q.y2[r], q.z2[r]};
+    w.id = q.tri[r];
+    const uint32_t xy = q.box_xy[r], wh = q.box_wh[r];
+    w.bx0 = xy & 0xFFFF;
+    w.by0 = xy >> 16;
+    const int bw = wh & 0xFFFF, bh = wh >> 16;
+    w.bx1 = w.bx0 + bw;
+    w.by1 = w.by0 + bh;
+    w.nbx = (bw + 3) >> 2;
+    w.nblk = w.nbx * ((bh + 3) >> 2);
+    return w;
+}
+
+#ifdef CRENDER_STAMPS
+// Diagnostic build only: per-tile phase timestamps (s_memtime) written to a buffer of their
+// own that no kernel reads.  8 words per tile: t_start, t_ready, t_swept, t_end, list length,
+// hw id, batches, unused.
+__device__ unsigned long long *g_stamps = nullptr;
+#define CR_STAMP(slot)                                                             \
+    do {                                                                           \
+        if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)tile * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define CR_STAMP(slot) do { } while (0)
+#endif
+
 template <int TS, bool CLEAR>
 __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ proj,
                                                      const float *__restrict__ col,
@@ -357,20 +452,43 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ p
                                                      const uint32_t *__restrict__ entries,
                                                      uint32_t capacity, float *__restrict__ zb,
                                                      float *__restrict__ cb, float *__restrict__ nb,
-                                                     int32_t *__restrict__ win, Geom G)
+                                                     int32_t *__restrict__ win, Geom G, int dbg)
 {
     __shared__ unsigned long long key[TS * TS];
     __shared__ WorkQueue q;
-    // queue fill counters, double-buffered by batch parity so that two barriers per
-    // batch suffice: [parity][0] = small boxes, [parity][1] = large boxes
-    __shared__ uint32_t q_count[2][2];
 
-    const int tile = xcd_band_tile(blockIdx.x, G.ntiles);
+    const int tile = (dbg & 8) ? xcd_band_tile(blockIdx.x, G.ntiles) : (int)blockIdx.x;
     const int tx = tile % G.ntx, ty = tile / G.ntx;
     const int X0 = tx * TS, Y0 = G.y0 + ty * TS;
     const int X1 = (X0 + TS < G.W) ? (X0 + TS) : G.W;
     const int Y1 = (Y0 + TS < G.y1) ? (Y0 + TS) : G.y1;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    CR_STAMP(0);
+    // the tile's triangle list: a run of the scanned bin array, or (direct bins, offs == null)
+    // a fixed-capacity slab whose fill count k_setup left in cursor[tile]
+    uint32_t beg, end;
+    if (offs) {
+        beg = offs[tile];
+        end = offs[tile + 1];
+        if (end > capacity) end = capacity;
+        if (beg > end) beg = end;
+    } else {
+        const uint32_t n = cursor[tile];
+        beg = (uint32_t)tile * capacity;
+        end = beg + (n < capacity ? n : capacity);
+    }
+    if (dbg & 1) end = beg;   // ablation: no coverage work
+
+    // first batch of the tile's list: index + projected vertices straight into registers
+    uint32_t cur_id = 0;
+    TriXYZ cur_t{};
+    bool cur_ok = beg + tid < end;
+    if (cur_ok) {
+        cur_id = entries[beg + tid];
+        cur_t = load_tri(proj + (size_t)cur_id * 9);
+    }
 
     // depth keys of the tile: the prior buffer value (or the cleared value) per pixel
     const unsigned long long key_clear = make_key(zord(1e6f), KEY_LOW_PRIOR);
@@ -382,89 +500,103 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ p
         }
         key[p] = k;
     }
+    CR_STAMP(1);
+#ifdef CRENDER_STAMPS
+    if (g_stamps && tid == 0) g_stamps[(size_t)tile * 8 + 4] = end - beg;
+#endif
 
-    uint32_t beg = offs[tile], end = offs[tile + 1];
-    if (end > capacity) end = capacity;
-    if (beg > end) beg = end;
-    if (tid == 0) {
-        cursor[tile] = 0;  // restore the all-zero invariant for the next frame
-        q_count[0][0] = q_count[0][1] = q_count[1][0] = q_count[1][1] = 0;
-    }
-    __syncthreads();  // keys and counters initialised
-
-    int parity = 0;
-    for (uint32_t base = beg; base < end; base += kThreads, parity ^= 1) {
-        uint32_t &n_small = q_count[parity][0], &n_large = q_count[parity][1];
-        const uint32_t i = base + tid;
-        if (i < end) {
-            const uint32_t id = entries[i];
-            const TriXYZ t = load_tri(proj + (size_t)id * 9);
+    for (uint32_t base = beg; base < end; base += kThreads) {
+        // ---- queue this batch: one record per thread, slot = thread index --------------
+        uint32_t box_xy = 0, box_wh = 0;
+        if (cur_ok) {
             int xl, xr, yt, yb;
-            pixel_box(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2, G.W, G.H, xl, xr, yt, yb);
+            pixel_box(cur_t.x0, cur_t.y0, cur_t.x1, cur_t.y1, cur_t.x2, cur_t.y2, G.W, G.H, xl, xr, yt, yb);
             if (xl < X0) xl = X0;
             if (xr > X1) xr = X1;
             if (yt < Y0) yt = Y0;
             if (yb > Y1) yb = Y1;
             if (xl < xr && yt < yb) {
-                const int bw = xr - xl, bh = yb - yt;
-                // small boxes fill the queue from the front, large ones from the back
-                uint32_t slot;
-                if (bw <= 8 && bh <= 8) slot = atomicAdd(&n_small, 1u);
-                else slot = kThreads - 1 - atomicAdd(&n_large, 1u);
-                q.x0[slot] = t.x0; q.y0[slot] = t.y0; q.z0[slot] = t.z0;
-                q.x1[slot] = t.x1; q.y1[slot] = t.y1; q.z1[slot] = t.z1;
-                q.x2[slot] = t.x2; q.y2[slot] = t.y2; q.z2[slot] = t.z2;
-                q.tri[slot] = id;
-                q.box_xy[slot] = (uint32_t)xl | ((uint32_t)yt << 16);
-                q.box_wh[slot] = (uint32_t)bw | ((uint32_t)bh << 16);
+                box_xy = (uint32_t)xl | ((uint32_t)yt << 16);
+                box_wh = (uint32_t)(xr - xl) | ((uint32_t)(yb - yt) << 16);
             }
         }
+        // wave-inclusive scan of the block counts
+        const uint32_t my_blocks = (uint32_t)blocks_of(box_wh);
+        uint32_t incl = my_blocks;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        // previous batch's sweeps must be over before the queue is overwritten; this
+        // barrier also orders the key initialisation before the first sweep
+        __syncthreads();
+        q.x0[tid] = cur_t.x0; q.y0[tid] = cur_t.y0; q.z0[tid] = cur_t.z0;
+        q.x1[tid] = cur_t.x1; q.y1[tid] = cur_t.y1; q.z1[tid] = cur_t.z1;
+        q.x2[tid] = cur_t.x2; q.y2[tid] = cur_t.y2; q.z2[tid] = cur_t.z2;
+        q.tri[tid] = cur_id;
+        q.box_xy[tid] = box_xy;
+        q.box_wh[tid] = box_wh;
+        q.blk_scan[tid] = incl - my_blocks;
+        if (lane == 63) q.wave_blocks[wave] = incl;
         __syncthreads();  // queue complete
-        const int ns = (int)n_small, nl = (int)n_large;
-        // the other parity's counters were last read before the previous batch's closing
-        // barrier and are next written after this batch's closing barrier
-        if (tid == 0) q_count[parity ^ 1][0] = q_count[parity ^ 1][1] = 0;
 
-        // small boxes: one 16-lane group per record, 4x4 pixel steps
+        // next batch: issue its loads now, they complete under the sweeps
+        const uint32_t nxt = base + kThreads + tid;
+        cur_ok = nxt < end;
+        if (cur_ok) {
+            cur_id = entries[nxt];
+            cur_t = load_tri(proj + (size_t)cur_id * 9);
+        }
+
+        // ---- sweep: the batch's blocks, flattened, split evenly over the 16 lane groups ---
         {
             const int grp = tid >> 4, l = tid & 15, lx = l & 3, ly = l >> 2;
-            for (int r = grp; r < ns; r += kThreads / 16) {
-                const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
-                               q.x2[r], q.y2[r], q.z2[r]};
-                const uint32_t id = q.tri[r];
-                const int bx0 = q.box_xy[r] & 0xFFFF, by0 = q.box_xy[r] >> 16;
-                const int bx1 = bx0 + (int)(q.box_wh[r] & 0xFFFF), by1 = by0 + (int)(q.box_wh[r] >> 16);
-                for (int yy = by0 + ly; yy < by1; yy += 4)
-                    for (int xx = bx0 + lx; xx < bx1; xx += 4) {
-                        unsigned long long k;
-                        if (fragment(t, id, xx, yy, k)) {
-                            lds_key_min(&key[(yy - Y0) * TS + (xx - X0)], k);
-                        }
+            uint32_t wo[kThreads / 64 + 1];
+            wo[0] = 0;
+#pragma unroll
+            for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + q.wave_blocks[w];
+            const int total = (int)wo[kThreads / 64];
+            const int chunk = (total + 15) >> 4;
+            int p = grp * chunk;
+            const int pend = (p + chunk < total) ? (p + chunk) : total;
+            if (p < pend) {
+                // locate the record holding flattened block p: wavefront, then slot within it
+                int w = 0;
+#pragma unroll
+                for (int v = 1; v < kThreads / 64; ++v)
+                    if ((uint32_t)p >= wo[v]) w = v;
+                const uint32_t pl = (uint32_t)p - wo[w];
+                int lo = w * 64, n = 64;   // last slot in [lo, lo + 64) with blk_scan <= pl
+                while (n > 1) {
+                    const int half = n >> 1;
+                    if (q.blk_scan[lo + half] <= pl) lo += half;
+                    n -= half;
+                }
+                int r = lo;
+                Work wk = load_work(q, r);
+                int b = (int)(pl - q.blk_scan[r]);
+                int by = (int)(((float)b + 0.5f) * (1.0f / (float)wk.nbx)), bx = b - by * wk.nbx;
+                for (;;) {
+                    const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
+                    unsigned long long k;
+                    if (x < wk.bx1 && y < wk.by1 && fragment(wk.t, wk.id, x, y, k))
+                        lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                    if (++p >= pend) break;
+                    if (++b < wk.nblk) {
+                        if (++bx == wk.nbx) { bx = 0; ++by; }
+                    } else {
+                        // p < pend guarantees a later record with blocks
+                        do { wk = load_work(q, ++r); } while (wk.nblk == 0);
+                        b = bx = by = 0;
                     }
+                }
             }
         }
-        // large boxes: one wavefront per record, 8x8 pixel steps
-        {
-            const int wave = tid >> 6, l = tid & 63, lx = l & 7, ly = l >> 3;
-            for (int j = wave; j < nl; j += kThreads / 64) {
-                const int r = kThreads - 1 - j;
-                const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
-                               q.x2[r], q.y2[r], q.z2[r]};
-                const uint32_t id = q.tri[r];
-                const int bx0 = q.box_xy[r] & 0xFFFF, by0 = q.box_xy[r] >> 16;
-                const int bx1 = bx0 + (int)(q.box_wh[r] & 0xFFFF), by1 = by0 + (int)(q.box_wh[r] >> 16);
-                for (int yy = by0 + ly; yy < by1; yy += 8)
-                    for (int xx = bx0 + lx; xx < bx1; xx += 8) {
-                        unsigned long long k;
-                        if (fragment(t, id, xx, yy, k)) {
-                            lds_key_min(&key[(yy - Y0) * TS + (xx - X0)], k);
-                        }
-                    }
-            }
-        }
-        __syncthreads();  // sweeps done: the next batch may overwrite the queue
     }
+    __syncthreads();
 
+    CR_STAMP(2);
     // resolve: every pixel of the tile is written at most once (exactly once if CLEAR)
     for (int p = tid; p < TS * TS; p += kThreads) {
         const int x = X0 + (p % TS), y = Y0 + (p / TS);
@@ -481,9 +613,19 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ p
             continue;
         }
         const uint32_t id = 0xFFFFFFFEu - low;
+        if (dbg & 2) {   // ablation: no shading
+            zb[pix] = (float)id;
+            cb[pix * 3] = 1.0f; cb[pix * 3 + 1] = 1.0f; cb[pix * 3 + 2] = 1.0f;
+            nb[pix * 3] = 1.0f; nb[pix * 3 + 1] = 1.0f; nb[pix * 3 + 2] = 1.0f;
+            continue;
+        }
         shade_and_store(proj, col, nrm, id, x, y, pix, zb, cb, nb);
         if (win) win[pix] = (int32_t)id;
     }
+    // every thread has read cursor[tile] before the barrier that precedes the resolve:
+    // restore the all-zero invariant of the per-tile counters for the next frame
+    if (tid == 0) cursor[tile] = 0;
+    CR_STAMP(3);
 }
 
 // ---- second implementation: global 64-bit atomics ---------------------------------
@@ -583,7 +725,7 @@ size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
 
 int pick_tile(int H, int W, int tile)
 {
-    if (tile == 32 || tile == 64) return tile;
+    if (tile == 16 || tile == 32 || tile == 64) return tile;
     return ((int64_t)H * W <= (int64_t)2048 * 2048) ? 32 : 64;
 }
 
@@ -592,8 +734,15 @@ struct Layout {
     Geom g;
     int64_t max_T;
     int64_t capacity;
-    size_t off_hdr, off_count, off_offs, off_trange, off_proj, off_entries, total;
+    int64_t direct_cap;   // entries per tile of the direct bins, 0 = scene too large for them
+    size_t off_hdr, off_count, off_offs, off_trange, off_proj, off_entries, off_direct, total;
 };
+
+// Direct bins are for small scenes (the README benchmark): one launch fewer than the
+// count / scan / fill path matters when a frame takes tens of microseconds.
+constexpr int64_t kDirectMaxTriangles = 1 << 16;
+constexpr int kDirectMaxTiles = 8192;   // the block-level cursors live in an LDS histogram
+constexpr int64_t kDirectCap = 1024;
 
 bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int tile, Layout &L)
 {
@@ -616,6 +765,8 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
     L.off_trange = o;  o = align_up(o + sizeof(uint2) * (size_t)max_T);
     L.off_proj = o;    o = align_up(o + sizeof(float) * 9 * (size_t)max_T);
     L.off_entries = o; o = align_up(o + sizeof(uint32_t) * (size_t)cap);
+    L.direct_cap = (max_T <= kDirectMaxTriangles && L.g.ntiles <= kDirectMaxTiles) ? kDirectCap : 0;
+    L.off_direct = o;  o = align_up(o + sizeof(uint32_t) * (size_t)L.g.ntiles * (size_t)L.direct_cap);
     L.total = o;
     return true;
 }
@@ -629,6 +780,9 @@ struct crender_plan {
     // before the binning passes, before k_raster, after k_raster
     std::vector<hipEvent_t> events;
     int timed_frames = 0;
+    bool direct_ok = true;        // cleared once a frame overflowed the direct bins
+    bool last_frame_direct = false;
+    uint32_t *direct() const { return reinterpret_cast<uint32_t *>(ws + L.off_direct); }
     bool timing() const { return !events.empty() && (size_t)(timed_frames + 1) * 3 <= events.size(); }
     hipEvent_t ev(int k) const { return events[(size_t)timed_frames * 3 + k]; }
     uint32_t *hdr() const { return reinterpret_cast<uint32_t *>(ws + L.off_hdr); }
@@ -661,55 +815,74 @@ int run_tile_frame(crender_plan *plan, bool project, const float *d_tri, const f
     const Geom G = L.g;
     const float *proj = project ? plan->proj() : d_tri;
     const bool timing = plan->timing();
+    static const int dbg = std::getenv("CRENDER_DEBUG") ? std::atoi(std::getenv("CRENDER_DEBUG")) : 0;
+    const bool direct = L.direct_cap > 0 && plan->direct_ok && !(flags & CRENDER_NO_DIRECT_BINS) &&
+                        !(dbg & 16);
+    plan->last_frame_direct = direct;
     if (timing) CR_HIP(hipEventRecord(plan->ev(0), s));
-    if (T > 0) {
-        // contiguous chunk of triangles per block, a multiple of the block size
-        int64_t nblk = (T + kThreads - 1) / kThreads;
-        if (nblk > 2048) nblk = 2048;
-        int64_t chunk = (T + nblk - 1) / nblk;
+
+    // contiguous chunk of triangles per block, a multiple of the block size
+    auto chunking = [T](int64_t max_blocks, int64_t &nblk, int64_t &chunk) {
+        nblk = (T + kThreads - 1) / kThreads;
+        if (nblk > max_blocks) nblk = max_blocks;
+        chunk = (T + nblk - 1) / nblk;
         chunk = (chunk + kThreads - 1) / kThreads * kThreads;
         nblk = (T + chunk - 1) / chunk;
-        const bool lds_hist = G.ntiles <= kMaxLdsHistTiles;
-        const size_t hist_bytes = lds_hist ? sizeof(uint32_t) * (size_t)((G.ntiles + 3) & ~3) : 0;
+    };
+    const bool lds_hist = G.ntiles <= kMaxLdsHistTiles;
+    if (T > 0) {
+        int64_t nblk, chunk;
+        chunking(2048, nblk, chunk);
+        const int bin = direct ? kBinDirect : (lds_hist ? kBinCountLds : kBinCountGlobal);
+        const size_t hist_bytes = bin != kBinCountGlobal ? sizeof(uint32_t) * (size_t)((G.ntiles + 3) & ~3) : 0;
         const size_t setup_lds = hist_bytes + sizeof(float) * kThreads * 9 * 2;
-#define CR_SETUP(PROJ, HIST)                                                                       \
-    hipLaunchKernelGGL((k_setup<TS, PROJ, HIST>), dim3((unsigned)nblk), dim3(kThreads), setup_lds, \
-                       s, d_tri, d_nrm, plan->proj(), plan->trange(), plan->count(), T, chunk, P, G)
-        if (project) { if (lds_hist) CR_SETUP(true, true); else CR_SETUP(true, false); }
-        else         { if (lds_hist) CR_SETUP(false, true); else CR_SETUP(false, false); }
+#define CR_SETUP(PROJ, BIN)                                                                          \
+    hipLaunchKernelGGL((k_setup<TS, PROJ, BIN>), dim3((unsigned)nblk), dim3(kThreads), setup_lds, s, \
+                       d_tri, d_nrm, plan->proj(), plan->trange(), plan->count(), plan->direct(),    \
+                       (uint32_t)L.direct_cap, plan->hdr(), T, chunk, P, G)
+        if (project) {
+            if (bin == kBinDirect) CR_SETUP(true, kBinDirect);
+            else if (bin == kBinCountLds) CR_SETUP(true, kBinCountLds);
+            else CR_SETUP(true, kBinCountGlobal);
+        } else {
+            if (bin == kBinDirect) CR_SETUP(false, kBinDirect);
+            else if (bin == kBinCountLds) CR_SETUP(false, kBinCountLds);
+            else CR_SETUP(false, kBinCountGlobal);
+        }
 #undef CR_SETUP
         CR_LAUNCH_CHECK("k_setup");
     }
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, plan->count(), plan->offs(), plan->hdr(),
-                       G.ntiles);
-    CR_LAUNCH_CHECK("k_scan");
-    if (T > 0) {
-        int64_t nblk = (T + kThreads - 1) / kThreads;
-        if (nblk > 1024) nblk = 1024;
-        int64_t chunk = (T + nblk - 1) / nblk;
-        chunk = (chunk + kThreads - 1) / kThreads * kThreads;
-        nblk = (T + chunk - 1) / chunk;
-        const bool lds_hist = G.ntiles <= kMaxLdsHistTiles;
-        const size_t lds = lds_hist ? sizeof(uint32_t) * (size_t)G.ntiles : 0;
-        if (lds_hist)
-            hipLaunchKernelGGL((k_fill<true>), dim3((unsigned)nblk), dim3(kThreads), lds, s,
-                               plan->trange(), plan->offs(), plan->count(), plan->entries(),
-                               (uint32_t)L.capacity, T, chunk, G);
-        else
-            hipLaunchKernelGGL((k_fill<false>), dim3((unsigned)nblk), dim3(kThreads), 0, s,
-                               plan->trange(), plan->offs(), plan->count(), plan->entries(),
-                               (uint32_t)L.capacity, T, chunk, G);
-        CR_LAUNCH_CHECK("k_fill");
+    if (!direct) {
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, plan->count(), plan->offs(), plan->hdr(),
+                           G.ntiles);
+        CR_LAUNCH_CHECK("k_scan");
+        if (T > 0) {
+            int64_t nblk, chunk;
+            chunking(1024, nblk, chunk);
+            const size_t lds = lds_hist ? sizeof(uint32_t) * (size_t)G.ntiles : 0;
+            if (lds_hist)
+                hipLaunchKernelGGL((k_fill<true>), dim3((unsigned)nblk), dim3(kThreads), lds, s,
+                                   plan->trange(), plan->offs(), plan->count(), plan->entries(),
+                                   (uint32_t)L.capacity, T, chunk, G);
+            else
+                hipLaunchKernelGGL((k_fill<false>), dim3((unsigned)nblk), dim3(kThreads), 0, s,
+                                   plan->trange(), plan->offs(), plan->count(), plan->entries(),
+                                   (uint32_t)L.capacity, T, chunk, G);
+            CR_LAUNCH_CHECK("k_fill");
+        }
     }
     if (timing) CR_HIP(hipEventRecord(plan->ev(1), s));
+    const uint32_t *offs = direct ? nullptr : plan->offs();
+    const uint32_t *list = direct ? plan->direct() : plan->entries();
+    const uint32_t cap = direct ? (uint32_t)L.direct_cap : (uint32_t)L.capacity;
     if (flags & CRENDER_FUSED_CLEAR)
         hipLaunchKernelGGL((k_raster<TS, true>), dim3((unsigned)G.ntiles), dim3(kThreads), 0, s, proj,
-                           d_col, d_nrm, plan->offs(), plan->count(), plan->entries(),
-                           (uint32_t)L.capacity, d_z, d_color, d_normal, d_winner, G);
+                           d_col, d_nrm, offs, plan->count(), list, cap, d_z, d_color, d_normal,
+                           d_winner, G, dbg);
     else
         hipLaunchKernelGGL((k_raster<TS, false>), dim3((unsigned)G.ntiles), dim3(kThreads), 0, s, proj,
-                           d_col, d_nrm, plan->offs(), plan->count(), plan->entries(),
-                           (uint32_t)L.capacity, d_z, d_color, d_normal, d_winner, G);
+                           d_col, d_nrm, offs, plan->count(), list, cap, d_z, d_color, d_normal,
+                           d_winner, G, dbg);
     CR_LAUNCH_CHECK("k_raster");
     if (timing) {
         CR_HIP(hipEventRecord(plan->ev(2), s));
@@ -731,6 +904,9 @@ int tile_frame(crender_plan *plan, bool project, const float *d_tri, const float
     std::memset(&P, 0, sizeof P);
     if (project) P = make_proj(P16, plan->L.g.W, plan->L.g.H);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (plan->L.ts == 16)
+        return run_tile_frame<16>(plan, project, d_tri, d_col, d_nrm, T, P, d_z, d_color, d_normal,
+                                  d_winner, flags, s);
     if (plan->L.ts == 32)
         return run_tile_frame<32>(plan, project, d_tri, d_col, d_nrm, T, P, d_z, d_color, d_normal,
                                   d_winner, flags, s);
@@ -742,6 +918,9 @@ int tile_frame(crender_plan *plan, bool project, const float *d_tri, const float
 
 // =========================== C ABI ================================================
 extern "C" {
+#ifdef CRENDER_STAMPS
+CRENDER_API int crender_debug_set_stamps(void *d_buf);
+#endif
 
 int crender_abi_version(void) { return CRENDER_ABI_VERSION; }
 
@@ -876,13 +1055,28 @@ int crender_plan_timing_end(crender_plan *plan, void *stream, int *frames, doubl
 int crender_plan_last_bin_usage(crender_plan *plan, void *stream, int64_t *needed, int64_t *capacity)
 {
     if (!plan) return fail(CRENDER_EINVAL, "null plan");
-    uint32_t h = 0;
+    uint32_t h[2] = {0, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    CR_HIP(hipMemcpyAsync(&h, plan->hdr(), sizeof h, hipMemcpyDeviceToHost, s));
+    CR_HIP(hipMemcpyAsync(h, plan->hdr(), sizeof h, hipMemcpyDeviceToHost, s));
     CR_HIP(hipStreamSynchronize(s));
-    if (needed) *needed = h;
+    if (plan->last_frame_direct) {
+        // direct bins: per-tile figures.  h[1] is sticky: the longest list that did not fit
+        // (0xFFFFFFFF = a triangle spans too many tiles).  On overflow this plan switches to
+        // the count / scan / fill path for good; the caller renders the frame again.
+        const int64_t cap = plan->L.direct_cap;
+        if (h[1] > (uint32_t)cap) plan->direct_ok = false;  // h[1] stays set: the answer is repeatable
+        if (needed) *needed = h[1] > (uint32_t)cap ? (int64_t)h[1] : 0;
+        if (capacity) *capacity = cap;
+        return CRENDER_OK;
+    }
+    if (needed) *needed = h[0];
     if (capacity) *capacity = plan->L.capacity;
     return CRENDER_OK;
+}
+
+int crender_plan_last_frame_direct(crender_plan *plan)
+{
+    return plan && plan->last_frame_direct ? 1 : 0;
 }
 
 int crender_raster(crender_plan *plan, const float *d_tri_proj, const float *d_col, const float *d_nrm,
@@ -900,6 +1094,16 @@ int crender_render_model(crender_plan *plan, const float *d_tri, const float *d_
     return tile_frame(plan, true, d_tri, d_col, d_nrm, T, P16, d_z, d_color, d_normal, d_winner, flags,
                       stream);
 }
+
+#ifdef CRENDER_STAMPS
+// diagnostic build: point the kernels at a stamp buffer (ntiles * 8 u64), or detach with null
+int crender_debug_set_stamps(void *d_buf)
+{
+    unsigned long long *p = static_cast<unsigned long long *>(d_buf);
+    CR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof p));
+    return CRENDER_OK;
+}
+#endif
 
 size_t crender_atomic_scratch_bytes(int H, int W)
 {

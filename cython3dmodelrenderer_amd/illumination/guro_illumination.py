@@ -30,6 +30,7 @@ class GuroIllumination(IlluminationDrawer):
         lib = _capi.load()
         light = (C.c_float * 3)(*[float(v) for v in self.light_direction])
         filler._push_host_edits()
+        filler.synchronize()      # the frame must be complete (bin lists may grow and redo it)
         _capi.check(lib.crender_guro_illumination(
             filler.color_buffer.data_ptr(), filler.normals_buffer.data_ptr(), light,
             filler.h, filler.w, filler.y0, filler.y1, filler._stream()), "crender_guro_illumination")

@@ -98,6 +98,9 @@ class Plan:
             self._lib.crender_plan_destroy(self.handle)
             self.handle = C.c_void_p()
 
+    def last_frame_direct(self):
+        return bool(self._lib.crender_plan_last_frame_direct(self.handle))
+
     def bin_usage(self):
         need, cap = C.c_int64(), C.c_int64()
         with torch.cuda.device(self.device):
@@ -116,24 +119,28 @@ def _tri_ptrs(tri, col, nrm):
     return tri.data_ptr(), col.data_ptr(), nrm.data_ptr(), tri.shape[0]
 
 
-def raster(plan, proj, col, nrm, fb, clear=False):
+def _flags(clear, direct_bins):
+    return (_capi.FUSED_CLEAR if clear else 0) | (0 if direct_bins else _capi.NO_DIRECT_BINS)
+
+
+def raster(plan, proj, col, nrm, fb, clear=False, direct_bins=True):
     """K2 (.pyx:177-244), tile path, on already projected triangles."""
     p, c, n, T = _tri_ptrs(proj, col, nrm)
     with torch.cuda.device(fb.device):
         _capi.check(plan._lib.crender_raster(
             plan.handle, p, c, n, T, fb.z.data_ptr(), fb.color.data_ptr(), fb.normals.data_ptr(),
             fb.winner.data_ptr() if fb.winner is not None else None,
-            _capi.FUSED_CLEAR if clear else 0, _stream(fb.device)), "crender_raster")
+            _flags(clear, direct_bins), _stream(fb.device)), "crender_raster")
 
 
-def render_model(plan, tri, col, nrm, P, fb, clear=False):
+def render_model(plan, tri, col, nrm, P, fb, clear=False, direct_bins=True):
     """render_model (.pyx:92-104): K1 fused into the binning pass + K2."""
     p, c, n, T = _tri_ptrs(tri, col, nrm)
     with torch.cuda.device(fb.device):
         _capi.check(plan._lib.crender_render_model(
             plan.handle, p, c, n, T, _capi.f32_16(P), fb.z.data_ptr(), fb.color.data_ptr(),
             fb.normals.data_ptr(), fb.winner.data_ptr() if fb.winner is not None else None,
-            _capi.FUSED_CLEAR if clear else 0, _stream(fb.device)), "crender_render_model")
+            _flags(clear, direct_bins), _stream(fb.device)), "crender_render_model")
 
 
 def raster_atomic(proj, col, nrm, fb, y0=0, y1=None, clear=False, keys=None):

@@ -90,6 +90,7 @@ class AdvancedPixelBufferFiller:
         self._inputs = None            # (tri, col, nrm) device tensors of the last frame
         self._input_key = None
         self._last_flags = 0
+        self._extra_flags = 0
         self._host = {}                # name -> numpy mirror handed out by a getter
         self._host_fresh = False       # mirrors equal the device buffers
         self._host_exposed = False     # a mirror was handed out and may have been edited
@@ -154,7 +155,7 @@ class AdvancedPixelBufferFiller:
             _capi.check(self._lib.crender_render_model(
                 self._plan, tri.data_ptr(), col.data_ptr(), nrm.data_ptr(), T, self._P,
                 self.z_buffer.data_ptr(), self.color_buffer.data_ptr(), self.normals_buffer.data_ptr(),
-                self._win_ptr(), flags, self._stream()), "crender_render_model")
+                self._win_ptr(), flags | self._extra_flags, self._stream()), "crender_render_model")
         self._last_flags = flags
         self._host_fresh = False
 
@@ -169,7 +170,11 @@ class AdvancedPixelBufferFiller:
         _capi.check(self._lib.crender_plan_last_bin_usage(self._plan, self._stream(), C.byref(need),
                                                           C.byref(cap)), "crender_plan_last_bin_usage")
         if need.value > cap.value:
-            self._ensure_plan(self._inputs[0].shape[0], capacity=int(need.value * 1.25) + 1024)
+            if self._lib.crender_plan_last_frame_direct(self._plan):
+                # this scene does not fit the small-scene direct bins: general path from now on
+                self._extra_flags |= _capi.NO_DIRECT_BINS
+            else:
+                self._ensure_plan(self._inputs[0].shape[0], capacity=int(need.value * 1.25) + 1024)
             self._launch(self._last_flags)
             self._check_bins()
 

@@ -52,7 +52,12 @@ enum {
      * __cinit__ leaves, .pyx:65-67) instead of reading it, and write every pixel of
      * the strip exactly once.  Equivalent to crender_clear followed by a flag-less
      * call, without the extra pass over the framebuffer. */
-    CRENDER_FUSED_CLEAR = 1u
+    CRENDER_FUSED_CLEAR = 1u,
+    /* Always bin through the count / scan / fill passes.  Without it, scenes of up to 65536
+     * triangles are binned by appending straight into fixed-capacity per-tile lists (one
+     * launch instead of three); a frame that does not fit reports so through
+     * crender_plan_last_bin_usage, and the plan then uses the general path by itself. */
+    CRENDER_NO_DIRECT_BINS = 2u
 };
 
 CRENDER_API int crender_abi_version(void);
@@ -91,10 +96,14 @@ CRENDER_API void crender_plan_destroy(crender_plan *plan);
 
 /* Synchronises `stream`, then reports the number of bin-list entries the most recent
  * crender_raster / crender_render_model on this plan needed and the capacity it had.
- * needed > capacity means that frame dropped fragments: recreate the plan with
- * bin_capacity >= needed and render again. */
+ * needed > capacity means that frame dropped fragments and must be rendered again:
+ *   - if crender_plan_last_frame_direct(plan) is 1 the frame used the direct bins (figures
+ *     are then per tile); the plan has switched itself to the general path, just re-render;
+ *   - otherwise recreate the plan with bin_capacity >= needed first. */
 CRENDER_API int crender_plan_last_bin_usage(crender_plan *plan, void *stream,
                                 int64_t *needed, int64_t *capacity);
+
+CRENDER_API int crender_plan_last_frame_direct(crender_plan *plan);
 
 /* Measurement aid (no reference counterpart): record HIP events on the frame's own
  * stream around the binning passes and around the raster kernel of each of the next

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Diagnostic: builds a -DCRENDER_STAMPS copy of the library, renders one workload and prints
+per-tile phase durations of k_raster (shader clocks from s_memtime).  Never used for timing
+claims: the stamped build is slower; only the SHARES are read."""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from cython3dmodelrenderer_amd import _build
+dbg_lib = "/tmp/libcrender_hip_stamps.so"
+subprocess.check_call([_build._hipcc()] + _build.HIPCC_FLAGS + ["-DCRENDER_STAMPS", "-o", dbg_lib,
+                       os.path.join(_build.SRC_DIR, "crender_hip.hip")], stderr=subprocess.DEVNULL)
+_build.LIB_PATH = dbg_lib
+import torch
+from cython3dmodelrenderer_amd import _capi, scenes
+from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+wl = sys.argv[1] if len(sys.argv) > 1 else "trex1024"; tile = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+tri, col, nrm, (H, W), fov = scenes.scene(wl)
+L = _capi.load()
+f = AdvancedPixelBufferFiller(H, W, fov=fov, tile=tile)
+f.render_arrays(tri, col, nrm, clear=True); f.synchronize()
+ts = tile or (32 if H * W <= 2048 * 2048 else 64)
+nt = ((W + ts - 1) // ts) * ((H + ts - 1) // ts)
+buf = torch.zeros(nt * 8, dtype=torch.int64, device="cuda:0")
+L.crender_debug_set_stamps.argtypes = [C.c_void_p]; L.crender_debug_set_stamps.restype = C.c_int
+for _ in range(3): f.render_frame()
+f.synchronize()
+assert L.crender_debug_set_stamps(buf.data_ptr()) == 0
+f.render_frame(); f.synchronize()
+L.crender_debug_set_stamps(None)
+s = buf.cpu().numpy().reshape(nt, 8).astype(np.int64)
+t0 = s[:, 0].min()
+start, ready, swept, end, n = s[:, 0] - t0, s[:, 1] - t0, s[:, 2] - t0, s[:, 3] - t0, s[:, 4]
+print(f"{wl} tile={ts} tiles={nt} kernel span {end.max()} clk; clocks are s_memtime ticks")
+print("start: p50 %d p90 %d max %d" % tuple(np.percentile(start, [50, 90, 100])))
+for name, d in (("init(start->ready)", ready - start), ("sweeps(ready->swept)", swept - ready), ("resolve(swept->end)", end - swept), ("total", end - start)):
+    act = n > 0
+    print(f"{name:22s} all: p50 {np.percentile(d,50):8.0f} p90 {np.percentile(d,90):8.0f} max {d.max():8d} | active tiles: p50 {np.percentile(d[act],50) if act.any() else 0:8.0f} p90 {np.percentile(d[act],90) if act.any() else 0:8.0f} max {d[act].max() if act.any() else 0:8d}")
+order = np.argsort(-(end - start))[:12]
+print("slowest tiles: tile list_len start init sweeps resolve end xcc/hwid")
+for i in order:
+    print(i, n[i], start[i], ready[i] - start[i], swept[i] - ready[i], end[i] - swept[i], end[i], hex(s[i, 5]))
+last = np.argsort(-end)[:8]
+print("last-finishing tiles:", [(int(i), int(n[i]), int(start[i]), int(end[i])) for i in last])
+# sweeps duration vs list length
+for lo, hi in ((1, 8), (8, 32), (32, 64), (64, 128), (128, 256), (256, 512), (512, 100000)):
+    m = (n >= lo) & (n < hi)
+    if m.any(): print(f"list [{lo},{hi}): tiles {m.sum():5d} sweeps p50 {np.percentile((swept-ready)[m],50):8.0f} max {(swept-ready)[m].max():8d}  resolve p50 {np.percentile((end-swept)[m],50):8.0f}")
