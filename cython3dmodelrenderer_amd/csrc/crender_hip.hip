@@ -288,35 +288,59 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
 
 // Exclusive scan of count[0..ntiles) into offs[0..ntiles]; count is zeroed (k_fill uses
 // it as the per-tile cursor); hdr[0] = total number of list entries this frame needs.
+// One 1024-thread workgroup walks the array in coalesced slabs of 4096 counters (4
+// consecutive ones per thread), the next slab's loads in flight while the current one is
+// scanned with wavefront shuffles + one LDS exchange of the 16 wavefront totals.
 __global__ __launch_bounds__(1024) void k_scan(uint32_t *__restrict__ count,
                                                uint32_t *__restrict__ offs,
                                                uint32_t *__restrict__ hdr, int ntiles)
 {
-    __shared__ uint32_t part[1024];
-    const int per = (ntiles + 1023) / 1024;
-    const int b = threadIdx.x * per;
-    const int e = (b + per < ntiles) ? (b + per) : ntiles;
-    uint32_t s = 0;
-    for (int i = b; i < e; ++i) s += count[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partial sums
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint32_t v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+    __shared__ uint32_t wave_total[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto load4 = [&](int base, uint32_t c[4]) {
+        const int i = base + tid * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = (i + k < ntiles) ? count[i + k] : 0u;
+    };
+    uint32_t cur[4], nxt[4];
+    load4(0, cur);
+    uint32_t carry = 0;
+    int buf = 0;
+    for (int base = 0; base < ntiles; base += 4096, buf ^= 1) {
+        if (base + 4096 < ntiles) load4(base + 4096, nxt);
+        const uint32_t s = cur[0] + cur[1] + cur[2] + cur[3];
+        uint32_t incl = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) wave_total[buf][wave] = incl;
+        __syncthreads();   // (the other buffer is free: its readers passed the previous barrier)
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t t = wave_total[buf][w];
+            if (w < wave) before += t;
+            total += t;
+        }
+        uint32_t run = carry + before + incl - s;
+        const int i = base + tid * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i + k < ntiles) {
+                offs[i + k] = run;
+                count[i + k] = 0;
+            }
+            run += cur[k];
+        }
+        carry += total;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
     }
-    uint32_t run = part[threadIdx.x] - s;
-    for (int i = b; i < e; ++i) {
-        const uint32_t c = count[i];
-        offs[i] = run;
-        run += c;
-        count[i] = 0;
-    }
-    if (threadIdx.x == 1023) {
-        offs[ntiles] = part[1023];
-        hdr[0] = part[1023];
+    if (tid == 0) {
+        offs[ntiles] = carry;
+        hdr[0] = carry;
     }
 }
 
@@ -726,7 +750,9 @@ size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
 int pick_tile(int H, int W, int tile)
 {
     if (tile == 16 || tile == 32 || tile == 64) return tile;
-    return ((int64_t)H * W <= (int64_t)2048 * 2048) ? 32 : 64;
+    // measured on MI355X (profiles/r01): small frames are latency-bound per tile and want many
+    // small tiles; large frames want 32-pixel tiles (full 128-B rows of z, 7 workgroups per CU)
+    return ((int64_t)H * W <= (int64_t)1024 * 1024) ? 16 : 32;
 }
 
 struct Layout {
