@@ -172,6 +172,41 @@ CR_DEV uint2 tile_range(const TriXYZ &t, const Geom &G)
     return make_uint2(tx0 | (tx1 << 16), ty0 | (ty1 << 16));
 }
 
+// Visit every tile of each lane's tile range (r.x == kNoTiles: none).  Narrow ranges are
+// walked by their own lane; a range wider than kWideTiles is walked by the whole wavefront,
+// 64 tiles at a time, so one screen-filling triangle does not serialise a wavefront behind a
+// single lane.  Must be called by all 64 lanes.  f(tile, payload of the range's owner); the
+// owner's payload is fetched while every lane is still active (a shuffle from a lane that has
+// left a divergent loop would read nothing).
+constexpr int kWideTiles = 16;
+template <typename F>
+CR_DEV void for_each_tile(uint2 r, uint32_t payload, int ntx, F f)
+{
+    const int lane = threadIdx.x & 63;
+    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+    if (r.x != kNoTiles) {
+        tx0 = r.x & 0xFFFF; tx1 = r.x >> 16; ty0 = r.y & 0xFFFF; ty1 = r.y >> 16;
+    }
+    const int mine = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+    const bool wide = mine > kWideTiles;
+    if (!wide)
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) f(ty * ntx + tx, payload);
+    unsigned long long m = __ballot(wide);
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const uint32_t rx = __shfl(r.x, src, 64), ry = __shfl(r.y, src, 64);
+        const uint32_t pay = __shfl(payload, src, 64);
+        const int sx0 = rx & 0xFFFF, sx1 = rx >> 16, sy0 = ry & 0xFFFF, sy1 = ry >> 16;
+        const int w = sx1 - sx0 + 1, n = w * (sy1 - sy0 + 1);
+        for (int i = lane; i < n; i += 64) {
+            const int dy = i / w;
+            f((sy0 + dy) * ntx + sx0 + (i - dy * w), pay);
+        }
+    }
+}
+
 // Binning mode of k_setup:
 //   kBinCountLds / kBinCountGlobal  count list lengths (LDS histogram or global atomics) and
 //                                   store each triangle's tile range for k_fill (scan path);
@@ -229,27 +264,20 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
                 r = tile_range<TS>(t, G);
             }
             if (BIN != kBinDirect) trange[b0 + threadIdx.x] = r;
-            if (r.x != kNoTiles) {
-                const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
-                if (BIN == kBinDirect) {
-                    // pass A of the direct bins: count this block's entries per tile in LDS
-                    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > kDirectMaxTilesPerTriangle) {
-                        atomicMax(&hdr[1], 0xFFFFFFFFu);  // sticky: this scene needs the scan path
-                        r.x = kNoTiles;
-                    } else {
-                        for (int ty = ty0; ty <= ty1; ++ty)
-                            for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&hist[ty * G.ntx + tx], 1u);
-                    }
-                } else {
-                    for (int ty = ty0; ty <= ty1; ++ty)
-                        for (int tx = tx0; tx <= tx1; ++tx) {
-                            if (LDS_HIST) atomicAdd(&hist[ty * G.ntx + tx], 1u);
-                            else atomicAdd(&count[ty * G.ntx + tx], 1u);
-                        }
+            if (BIN == kBinDirect && r.x != kNoTiles) {
+                const int ntl = (int)((r.x >> 16) - (r.x & 0xFFFF) + 1) * (int)((r.y >> 16) - (r.y & 0xFFFF) + 1);
+                if (ntl > kDirectMaxTilesPerTriangle) {
+                    atomicMax(&hdr[1], 0xFFFFFFFFu);  // sticky: this scene needs the scan path
+                    r.x = kNoTiles;
                 }
             }
             r_keep = r;
         }
+        // list lengths (pass A of the direct bins): LDS histogram or global counters
+        for_each_tile(r_keep, 0u, G.ntx, [&](int tile, uint32_t) {
+            if (LDS_HIST) atomicAdd(&hist[tile], 1u);
+            else atomicAdd(&count[tile], 1u);
+        });
         __syncthreads();
         if (PROJECT) stage_out(proj_out + b0 * 9, sv, n * 9);
         if (BIN == kBinDirect) {
@@ -260,17 +288,12 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
                 if (c) hist[i] = atomicAdd(&count[i], c);
             }
             __syncthreads();
-            if ((int)threadIdx.x < n && r_keep.x != kNoTiles) {
-                const uint2 r = r_keep;
-                const uint32_t id = (uint32_t)(b0 + threadIdx.x);
-                const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
-                for (int ty = ty0; ty <= ty1; ++ty)
-                    for (int tx = tx0; tx <= tx1; ++tx) {
-                        const int tile = ty * G.ntx + tx;
-                        const uint32_t slot = atomicAdd(&hist[tile], 1u);
-                        if (slot < dcap) dlist[(size_t)tile * dcap + slot] = id;
-                        else atomicMax(&hdr[1], slot + 1);
-                    }
+            {
+                for_each_tile(r_keep, (uint32_t)(b0 + threadIdx.x), G.ntx, [&](int tile, uint32_t id) {
+                    const uint32_t slot = atomicAdd(&hist[tile], 1u);
+                    if (slot < dcap) dlist[(size_t)tile * dcap + slot] = id;
+                    else atomicMax(&hdr[1], slot + 1);
+                });
             }
             __syncthreads();
             // cursors back to zero for the block's next batch
@@ -357,16 +380,15 @@ __global__ __launch_bounds__(kThreads) void k_fill(const uint2 *__restrict__ tra
     uint32_t *cur = reinterpret_cast<uint32_t *>(smem_raw);
     const int64_t c0 = (int64_t)blockIdx.x * chunk;
     const int64_t c1 = (c0 + chunk < T) ? (c0 + chunk) : T;
+    const uint2 none = make_uint2(kNoTiles, 0);
     if (LDS_HIST) {
         for (int i = threadIdx.x; i < G.ntiles; i += kThreads) cur[i] = 0;
         __syncthreads();
         // sweep 1: how many entries this block adds to each tile list
-        for (int64_t t = c0 + threadIdx.x; t < c1; t += kThreads) {
-            const uint2 r = trange[t];
-            if (r.x == kNoTiles) continue;
-            const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
-            for (int ty = ty0; ty <= ty1; ++ty)
-                for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&cur[ty * G.ntx + tx], 1u);
+        for (int64_t b0 = c0; b0 < c1; b0 += kThreads) {
+            const int64_t t = b0 + threadIdx.x;
+            for_each_tile(t < c1 ? trange[t] : none, 0u, G.ntx,
+                          [&](int tile, uint32_t) { atomicAdd(&cur[tile], 1u); });
         }
         __syncthreads();
         // reserve a contiguous run in every touched list
@@ -376,18 +398,14 @@ __global__ __launch_bounds__(kThreads) void k_fill(const uint2 *__restrict__ tra
         }
         __syncthreads();
     }
-    for (int64_t t = c0 + threadIdx.x; t < c1; t += kThreads) {
-        const uint2 r = trange[t];
-        if (r.x == kNoTiles) continue;
-        const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
-        for (int ty = ty0; ty <= ty1; ++ty)
-            for (int tx = tx0; tx <= tx1; ++tx) {
-                const int tile = ty * G.ntx + tx;
-                uint32_t pos;
-                if (LDS_HIST) pos = atomicAdd(&cur[tile], 1u);
-                else pos = offs[tile] + atomicAdd(&cursor[tile], 1u);
-                if (pos < capacity) entries[pos] = (uint32_t)t;
-            }
+    for (int64_t b0 = c0; b0 < c1; b0 += kThreads) {
+        const int64_t t = b0 + threadIdx.x;
+        for_each_tile(t < c1 ? trange[t] : none, (uint32_t)t, G.ntx, [&](int tile, uint32_t id) {
+            uint32_t pos;
+            if (LDS_HIST) pos = atomicAdd(&cur[tile], 1u);
+            else pos = offs[tile] + atomicAdd(&cursor[tile], 1u);
+            if (pos < capacity) entries[pos] = id;
+        });
     }
 }
 
@@ -424,9 +442,11 @@ struct WorkQueue {
     uint32_t wave_blocks[kThreads / 64];
 };
 
-// The record a 16-lane group is sweeping.
+// The record a 16-lane group is sweeping.  T = TriXYZ (small records: the edge constants are
+// hoisted by the compiler) or TriSetup (large records: with the two division shortcuts).
+template <typename T>
 struct Work {
-    TriXYZ t;
+    T s;
     uint32_t id;
     int bx0, by0, bx1, by1;  // clipped pixel box [bx0, bx1) x [by0, by1)
     int nbx, nblk;           // 4x4 blocks across, in total
@@ -438,10 +458,10 @@ CR_DEV int blocks_of(uint32_t box_wh)
     return ((bw + 3) >> 2) * ((bh + 3) >> 2);
 }
 
-CR_DEV Work load_work(const WorkQueue &q, int r)
+template <typename T>
+CR_DEV Work<T> load_work(const WorkQueue &q, int r)
 {
-    Work w;
-    w.t = TriXYZ{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r], q.x2[r], q.y2[r], q.z2[r]};
+    Work<T> w;
     w.id = q.tri[r];
     const uint32_t xy = q.box_xy[r], wh = q.box_wh[r];
     w.bx0 = xy & 0xFFFF;
@@ -451,7 +471,28 @@ CR_DEV Work load_work(const WorkQueue &q, int r)
     w.by1 = w.by0 + bh;
     w.nbx = (bw + 3) >> 2;
     w.nblk = w.nbx * ((bh + 3) >> 2);
+    const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r], q.x2[r], q.y2[r], q.z2[r]};
+    if constexpr (sizeof(T) == sizeof(TriXYZ)) w.s = t;
+    else w.s = make_setup(t, w.nblk >= 16);
     return w;
+}
+
+// Flattened block index -> (wavefront, slot): the record holding block p of the batch.
+CR_DEV int find_record(const WorkQueue &q, const uint32_t *wo, int p, uint32_t &first_block)
+{
+    int w = 0;
+#pragma unroll
+    for (int v = 1; v < kThreads / 64; ++v)
+        if ((uint32_t)p >= wo[v]) w = v;
+    const uint32_t pl = (uint32_t)p - wo[w];
+    int lo = w * 64, n = 64;   // last slot in [lo, lo + 64) with blk_scan <= pl
+    while (n > 1) {
+        const int half = n >> 1;
+        if (q.blk_scan[lo + half] <= pl) lo += half;
+        n -= half;
+    }
+    first_block = pl - q.blk_scan[lo];
+    return lo;
 }
 
 #ifdef CRENDER_STAMPS
@@ -573,46 +614,80 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ p
             cur_t = load_tri(proj + (size_t)cur_id * 9);
         }
 
-        // ---- sweep: the batch's blocks, flattened, split evenly over the 16 lane groups ---
+        // ---- sweep: the batch's blocks, flattened and split evenly ---------------------------
         {
-            const int grp = tid >> 4, l = tid & 15, lx = l & 3, ly = l >> 2;
+            const int l = tid & 15, lx = l & 3, ly = l >> 2;
             uint32_t wo[kThreads / 64 + 1];
             wo[0] = 0;
 #pragma unroll
             for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + q.wave_blocks[w];
             const int total = (int)wo[kThreads / 64];
-            const int chunk = (total + 15) >> 4;
-            int p = grp * chunk;
-            const int pend = (p + chunk < total) ? (p + chunk) : total;
-            if (p < pend) {
-                // locate the record holding flattened block p: wavefront, then slot within it
-                int w = 0;
-#pragma unroll
-                for (int v = 1; v < kThreads / 64; ++v)
-                    if ((uint32_t)p >= wo[v]) w = v;
-                const uint32_t pl = (uint32_t)p - wo[w];
-                int lo = w * 64, n = 64;   // last slot in [lo, lo + 64) with blk_scan <= pl
-                while (n > 1) {
-                    const int half = n >> 1;
-                    if (q.blk_scan[lo + half] <= pl) lo += half;
-                    n -= half;
+            const int nrec = (int)((end - base) < (uint32_t)kThreads ? (end - base) : (uint32_t)kThreads);
+            if (total < 16 * nrec || (dbg & 128)) {
+                // Small records: each of the 16 lane groups takes one contiguous run of blocks,
+                // so a record is set up by (almost) one group only; tight loop, plain division.
+                const int chunk = (total + 15) >> 4;
+                int p = (tid >> 4) * chunk;
+                const int pend = (p + chunk < total) ? (p + chunk) : total;
+                if (p < pend) {
+                    uint32_t first;
+                    int r = find_record(q, wo, p, first);
+                    Work<TriXYZ> wk = load_work<TriXYZ>(q, r);
+                    int b = (int)first;
+                    int by = (int)(((float)b + 0.5f) * (1.0f / (float)wk.nbx)), bx = b - by * wk.nbx;
+                    for (;;) {
+                        const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
+                        unsigned long long k;
+                        if (x < wk.bx1 && y < wk.by1 && fragment(wk.s, wk.id, x, y, k))
+                            lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                        if (++p >= pend) break;
+                        if (++b < wk.nblk) {
+                            if (++bx == wk.nbx) { bx = 0; ++by; }
+                        } else {
+                            // p < pend guarantees a later record with blocks
+                            do { wk = load_work<TriXYZ>(q, ++r); } while (wk.nblk == 0);
+                            b = bx = by = 0;
+                        }
+                    }
                 }
-                int r = lo;
-                Work wk = load_work(q, r);
-                int b = (int)(pl - q.blk_scan[r]);
-                int by = (int)(((float)b + 0.5f) * (1.0f / (float)wk.nbx)), bx = b - by * wk.nbx;
-                for (;;) {
-                    const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
-                    unsigned long long k;
-                    if (x < wk.bx1 && y < wk.by1 && fragment(wk.t, wk.id, x, y, k))
-                        lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
-                    if (++p >= pend) break;
-                    if (++b < wk.nblk) {
-                        if (++bx == wk.nbx) { bx = 0; ++by; }
-                    } else {
-                        // p < pend guarantees a later record with blocks
-                        do { wk = load_work(q, ++r); } while (wk.nblk == 0);
-                        b = bx = by = 0;
+            } else {
+                // Large records (>= 16 blocks on average): each wavefront takes a contiguous
+                // quarter and its four groups every fourth block of it, so the four blocks a
+                // wavefront works on at a time are neighbours: their "surely outside" outcomes
+                // correlate and the divisions are skipped wave-wide (raster_math.h (1)); the
+                // divisions that remain use the hoisted reciprocal (raster_math.h (2)).
+                const int wchunk = (total + kThreads / 64 - 1) / (kThreads / 64);
+                int p = wave * wchunk + ((tid >> 4) & 3);
+                const int pend = ((wave + 1) * wchunk < total) ? ((wave + 1) * wchunk) : total;
+                const bool allow_rej = !(dbg & 32), allow_fast = !(dbg & 64);
+                if (p < pend) {
+                    uint32_t first;
+                    int r = find_record(q, wo, p, first);
+                    Work<TriSetup> wk = load_work<TriSetup>(q, r);
+                    int b = (int)first;
+                    float inv_nbx = 1.0f / (float)wk.nbx;
+                    for (;;) {
+                        const int by = (int)(((float)b + 0.5f) * inv_nbx), bx = b - by * wk.nbx;
+                        const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
+                        float n1, n2, n3;
+                        numerators(wk.s, x, y, n1, n2, n3);
+                        const bool live = x < wk.bx1 && y < wk.by1 &&
+                                          !(allow_rej && surely_outside(wk.s, n1, n2, n3));
+                        if (__any(live)) {   // wavefront-uniform
+                            unsigned long long k;
+                            if (live && fragment_from(wk.s, wk.id, n1, n2, n3, allow_fast, k))
+                                lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                        }
+                        p += 4;
+                        if (p >= pend) break;
+                        b += 4;
+                        if (b >= wk.nblk) {
+                            do {
+                                b -= wk.nblk;
+                                wk = load_work<TriSetup>(q, ++r);
+                            } while (b >= wk.nblk);
+                            inv_nbx = 1.0f / (float)wk.nbx;
+                        }
                     }
                 }
             }
@@ -716,6 +791,21 @@ __global__ __launch_bounds__(kThreads) void k_resolve_global(const float *__rest
         const uint32_t id = 0xFFFFFFFEu - low;
         shade_and_store(proj, col, nrm, id, (int)(pix % W), (int)(pix / W), pix, zb, cb, nb);
         if (win) win[pix] = (int32_t)id;
+    }
+}
+
+// ---- self-check hook: shortcut (2) of raster_math.h against the plain division ----------
+__global__ __launch_bounds__(kThreads) void k_divcheck(const float *__restrict__ num,
+                                                       const float *__restrict__ den,
+                                                       float *__restrict__ out_tail,
+                                                       float *__restrict__ out_div, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const float a = num[i], d = den[i];
+        const bool win = in_div_window(a) && in_div_window(d);
+        out_tail[i] = win ? div_tail(a, d, refined_rcp(d)) : a / d;
+        out_div[i] = a / d;
     }
 }
 
@@ -1130,6 +1220,18 @@ int crender_debug_set_stamps(void *d_buf)
     return CRENDER_OK;
 }
 #endif
+
+int crender_selfcheck_division(const float *d_num, const float *d_den, float *d_out_tail,
+                               float *d_out_div, int64_t n, void *stream)
+{
+    if (!d_num || !d_den || !d_out_tail || !d_out_div || n < 0)
+        return fail(CRENDER_EINVAL, "crender_selfcheck_division: bad argument");
+    if (n == 0) return CRENDER_OK;
+    hipLaunchKernelGGL(k_divcheck, dim3(grid_for((size_t)n, 8192)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), d_num, d_den, d_out_tail, d_out_div, (size_t)n);
+    CR_LAUNCH_CHECK("k_divcheck");
+    return CRENDER_OK;
+}
 
 size_t crender_atomic_scratch_bytes(int H, int W)
 {

@@ -156,6 +156,138 @@ CR_DEV bool fragment(const TriXYZ &t, uint32_t tri, int X, int Y, unsigned long 
     return true;
 }
 
+// ---- per-triangle setup for sample loops ------------------------------------------------
+// The sweeps evaluate many pixels of one triangle, so everything that depends on the
+// triangle only is computed once: the nine edge constants of mu.pyx:11-21, and two exact
+// shortcuts for the three divisions of mu.pyx:34.
+//
+// (1) Sign rejection.  b_k = num_k / den_k is certainly < 0 when num_k and den_k are finite
+//     with opposite signs, |num_k| >= 2^-60 and |den_k| <= 2^60 (the quotient is then at
+//     least 2^-120 in magnitude: it cannot round to -0).  rej_k below is +-1 with den_k's
+//     sign when den_k qualifies, else 0 (never reject); the test is num_k * rej_k < -2^-60.
+//     Samples where the test fails on all edges go through the division as before.
+//
+// (2) Division by a per-triangle denominator.  hipcc expands a correctly rounded f32 `/` to
+//       d' = div_scale(d), n' = div_scale(n), r = rcp(d'), r += fma(-d', r, 1) * r,
+//       q = n' * r, q += fma(-d', q, n') * r, res = div_fmas(fma(-d', q, n'), r, q),
+//       div_fixup(res, d, n).
+//     When |d| and |n| both lie in [2^-40, 2^40] neither div_scale changes its operand and
+//     div_fmas is a plain fma, so the reciprocal refinement depends on d alone and is hoisted;
+//     the per-sample tail (1 mul, 4 fma, div_fixup) performs the very same operations and
+//     rounds identically.  Outside the window (and for n == 0) the full `/` is used.
+//     tests/test_hip_parity_gpu.py::test_fast_division_is_bit_exact checks the tail against
+//     `/` on 2^27 operand pairs spanning the whole window.
+constexpr float kRejTiny = 8.67361738e-19f;     // 2^-60
+constexpr float kRejHuge = 1.15292150e+18f;     // 2^60
+constexpr float kDivLo = 9.09494702e-13f;       // 2^-40
+constexpr float kDivHi = 1.09951163e+12f;       // 2^40
+
+CR_DEV bool in_div_window(float a)
+{
+    const float m = fabsf(a);
+    return m >= kDivLo && m <= kDivHi;   // false for NaN, inf, 0
+}
+
+CR_DEV float refined_rcp(float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+
+// n / d for n, d inside the window, r = refined_rcp(d): the tail of hipcc's own expansion.
+CR_DEV float div_tail(float n, float d, float r)
+{
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    const float res = __builtin_fmaf(e, r, q);
+    return __builtin_amdgcn_div_fixupf(res, d, n);
+}
+
+struct TriSetup {
+    float x0, y0, x1, y1, x2, y2, z0, z1, z2;
+    float l01, l02, l03, l11, l12, l13, l21, l22, l23;
+    float r1, r2, r3;        // refined reciprocals of l03, l13, l23 (valid if fast)
+    float rej1, rej2, rej3;  // +-1 / 0, see (1)
+    bool fast;               // all three denominators inside the division window
+};
+
+CR_DEV float rej_sign(float den)
+{
+    const float m = fabsf(den);
+    if (!(m > 0.0f && m <= kRejHuge)) return 0.0f;   // 0, inf, NaN, too large: never reject
+    return den > 0.0f ? 1.0f : -1.0f;
+}
+
+// want_fast: prepare shortcut (2); not worth its ~20 instructions for a record that is
+// swept for only a few blocks.
+CR_DEV TriSetup make_setup(const TriXYZ &t, bool want_fast)
+{
+    TriSetup s;
+    s.x0 = t.x0; s.y0 = t.y0; s.x1 = t.x1; s.y1 = t.y1; s.x2 = t.x2; s.y2 = t.y2;
+    s.z0 = t.z0; s.z1 = t.z1; s.z2 = t.z2;
+    s.l01 = t.x1 - t.x2; s.l02 = t.y1 - t.y2;
+    s.l03 = s.l01 * (t.y0 - t.y2) - s.l02 * (t.x0 - t.x2);
+    s.l11 = t.x2 - t.x0; s.l12 = t.y2 - t.y0;
+    s.l13 = s.l11 * (t.y1 - t.y0) - s.l12 * (t.x1 - t.x0);
+    s.l21 = t.x0 - t.x1; s.l22 = t.y0 - t.y1;
+    s.l23 = s.l21 * (t.y2 - t.y1) - s.l22 * (t.x2 - t.x1);
+    s.fast = want_fast && in_div_window(s.l03) && in_div_window(s.l13) && in_div_window(s.l23);
+    s.r1 = s.r2 = s.r3 = 0.0f;
+    if (s.fast) {
+        s.r1 = refined_rcp(s.l03); s.r2 = refined_rcp(s.l13); s.r3 = refined_rcp(s.l23);
+    }
+    s.rej1 = rej_sign(s.l03); s.rej2 = rej_sign(s.l13); s.rej3 = rej_sign(s.l23);
+    return s;
+}
+
+// Numerators of the three barycentrics at pixel (X, Y), mu.pyx:34 before the division.
+CR_DEV void numerators(const TriSetup &s, int X, int Y, float &n1, float &n2, float &n3)
+{
+    const float fx = (float)X, fy = (float)Y;
+    n1 = s.l01 * (fy - s.y2) - s.l02 * (fx - s.x2);
+    n2 = s.l11 * (fy - s.y0) - s.l12 * (fx - s.x0);
+    n3 = s.l21 * (fy - s.y1) - s.l22 * (fx - s.x1);
+}
+
+// True if some barycentric is certainly negative (shortcut (1)); false decides nothing.
+CR_DEV bool surely_outside(const TriSetup &s, float n1, float n2, float n3)
+{
+    return (n1 * s.rej1 < -kRejTiny) || (n2 * s.rej2 < -kRejTiny) || (n3 * s.rej3 < -kRejTiny);
+}
+
+// The three quotients; `allow_fast` lets the caller switch shortcut (2) off (debug knob).
+CR_DEV void quotients(const TriSetup &s, float n1, float n2, float n3, bool allow_fast,
+                      float &b1, float &b2, float &b3)
+{
+    const float hi = fmaxf(fmaxf(fabsf(n1), fabsf(n2)), fabsf(n3));
+    const float lo = fminf(fminf(fabsf(n1), fabsf(n2)), fabsf(n3));
+    if (allow_fast && s.fast && lo >= kDivLo && hi <= kDivHi) {
+        b1 = div_tail(n1, s.l03, s.r1);
+        b2 = div_tail(n2, s.l13, s.r2);
+        b3 = div_tail(n3, s.l23, s.r3);
+    } else {
+        b1 = n1 / s.l03;
+        b2 = n2 / s.l13;
+        b3 = n3 / s.l23;
+    }
+}
+
+// Fragment test given the numerators (.pyx:215-221).
+CR_DEV bool fragment_from(const TriSetup &s, uint32_t tri, float n1, float n2, float n3,
+                          bool allow_fast, unsigned long long &key)
+{
+    float b1, b2, b3;
+    quotients(s, n1, n2, n3, allow_fast, b1, b2, b3);
+    if (b1 < 0.0f || b2 < 0.0f || b3 < 0.0f) return false;
+    const float z = interp(s.z0, s.z1, s.z2, b1, b2, b3);
+    if (z != z) return false;
+    key = fragment_key(z, tri);
+    return true;
+}
+
 // Load nine consecutive floats (one triangle of a [T][3][3] array).
 CR_DEV void load9(const float *__restrict__ p, float v[9])
 {

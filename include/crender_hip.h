@@ -141,6 +141,14 @@ CRENDER_API int crender_raster_atomic(const float *d_tri_proj, const float *d_co
                           int32_t *d_winner, int H, int W, int y0, int y1,
                           unsigned flags, void *d_keys, void *stream);
 
+/* Self-check hook (no reference counterpart).  The sweep divides many numerators by one
+ * per-triangle denominator and hoists the reciprocal refinement of hipcc's own division
+ * expansion out of the loop (csrc/raster_math.h, "shortcut (2)").  This entry point evaluates
+ * that shortcut (out_tail; plain division outside its operand window) and the plain `/`
+ * (out_div) element-wise so a test can require the two to be bit-identical. */
+CRENDER_API int crender_selfcheck_division(const float *d_num, const float *d_den, float *d_out_tail,
+                               float *d_out_div, int64_t n, void *stream);
+
 /* next row f1: GuroIllumination.draw_illumination
  * (crender/cy/illumination/guro_illumination.py:20-27) on device, in place on the
  * colour buffer: colour *= clip(n.l / (|n| + 1e-6), 0, 1), rows [y0, y1). */

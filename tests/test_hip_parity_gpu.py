@@ -333,6 +333,54 @@ def test_c_abi_argument_errors(hip):
                                  None) == _capi.ENOMEM
 
 
+def test_fast_division_is_bit_exact(hip):
+    """The sweep's division shortcut (raster_math.h (2)) must equal the correctly rounded `/`
+    for every operand pair inside its window [2^-40, 2^40]: random mantissas over every
+    exponent pair, extreme mantissas, and values straddling the window edges; both are also
+    compared with numpy's IEEE division."""
+    import torch
+    from cython3dmodelrenderer_amd import _capi
+    L = _capi.load()
+    rng = np.random.default_rng(2024)
+
+    def check(num, den):
+        a = torch.from_numpy(num).cuda(); d = torch.from_numpy(den).cuda()
+        o1 = torch.empty_like(a); o2 = torch.empty_like(a)
+        _capi.check(L.crender_selfcheck_division(a.data_ptr(), d.data_ptr(), o1.data_ptr(),
+                                                 o2.data_ptr(), a.numel(), None), "selfcheck")
+        torch.cuda.synchronize()
+        t, q = o1.cpu().numpy(), o2.cpu().numpy()
+        with np.errstate(all="ignore"):
+            ref = num / den
+        nan = np.isnan(ref)
+        assert (np.isnan(t) == nan).all() and (np.isnan(q) == nan).all()
+        assert_bit_equal(q[~nan], ref[~nan], "GPU `/` vs numpy")
+        assert_bit_equal(t[~nan], q[~nan], "division shortcut vs `/`")
+
+    # (a) every exponent pair of the window (and 3 beyond each edge) x random mantissas + signs
+    exps = np.arange(127 - 43, 127 + 44, dtype=np.uint32)
+    en, ed = np.meshgrid(exps, exps, indexing="ij")
+    reps = 4096
+    for chunk in range(8):
+        mn = rng.integers(0, 1 << 23, (en.size, reps // 8), dtype=np.uint32)
+        md = rng.integers(0, 1 << 23, (en.size, reps // 8), dtype=np.uint32)
+        sn = rng.integers(0, 2, mn.shape, dtype=np.uint32) << 31
+        sd = rng.integers(0, 2, mn.shape, dtype=np.uint32) << 31
+        num = (sn | (en.reshape(-1, 1) << 23) | mn).astype(np.uint32).view(np.float32).ravel()
+        den = (sd | (ed.reshape(-1, 1) << 23) | md).astype(np.uint32).view(np.float32).ravel()
+        check(np.ascontiguousarray(num), np.ascontiguousarray(den))
+    # (b) extreme mantissas on every exponent pair
+    mant = np.array([0, 1, 2, 0x400000, 0x3FFFFF, 0x7FFFFF, 0x7FFFFE, 0x555555, 0x2AAAAA], np.uint32)
+    e1, e2, m1, m2 = np.meshgrid(exps, exps, mant, mant, indexing="ij")
+    num = ((e1 << 23) | m1).astype(np.uint32).view(np.float32).ravel()
+    den = ((e2 << 23) | m2).astype(np.uint32).view(np.float32).ravel()
+    check(np.ascontiguousarray(num), np.ascontiguousarray(-den))
+    # (c) specials: zeros, denormals, inf, NaN go through the plain division inside the hook
+    sp = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, 3e38, np.inf, -np.inf, np.nan, 1.0, -3.0], np.float32)
+    a, b = np.meshgrid(sp, sp, indexing="ij")
+    check(np.ascontiguousarray(a.ravel()), np.ascontiguousarray(b.ravel()))
+
+
 # ---- the drop-in class ---------------------------------------------------------------
 class _M:  # any object with the three attributes is a model (SURVEY.md section 8b, duck typing)
     def __init__(self, tri, col, nrm):
