@@ -132,17 +132,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # ---- the timed region: exactly K steps ------------------------------------------
-    filler.timing_begin(args.steps)
+    # ---- the timed region: exactly K steps, nothing but the steps -------------------------
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    n_timed, bin_ms, raster_ms = filler.timing_end()
     need, cap = filler.bin_usage()
     assert need <= cap, "bin lists overflowed inside the timed region"
+
+    # ---- per-kernel durations: the same K steps again with HIP events on the frame's stream
+    # around the binning passes and around the raster kernel.  Kept out of the timed region
+    # above because the three event records cost ~11 us per frame on a ~35 us frame (measured:
+    # scripts/hostoverhead.py vs this loop); the events loop's own frame time is reported too.
+    filler.timing_begin(args.steps)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed_events = time.perf_counter() - t1
+    n_timed, bin_ms, raster_ms = filler.timing_end()
 
     if world > 1:
         t = torch.tensor([elapsed, raster_ms, bin_ms], dtype=torch.float64, device=device)
@@ -171,7 +182,9 @@ def main():
             "mtris_per_sec": T * fps / 1e6,
             "frame_algorithmic_bytes": algorithmic_bytes(T, H, W),
             "whole_frame_gbps": algorithmic_bytes(T, H, W) * fps / 1e9,
-            "kernel_ms": {"binning_passes": bin_ms, "raster": raster_ms, "timed_frames": n_timed},
+            "kernel_ms": {"binning_passes": bin_ms, "raster": raster_ms, "timed_frames": n_timed,
+                          "how": "HIP events on the frame's stream, second pass of K steps",
+                          "ms_per_step_with_events": elapsed_events / args.steps * 1e3},
             "roofline": {"kernel": "k_raster", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": abytes,

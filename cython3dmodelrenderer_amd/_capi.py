@@ -51,7 +51,8 @@ class CrenderError(RuntimeError):
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    # CRENDER_LIB: load another build of the same ABI (diagnostic builds, A/B variants)
+    return os.environ.get("CRENDER_LIB") or _build.LIB_PATH
 
 
 def load():

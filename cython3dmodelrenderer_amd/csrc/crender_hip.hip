@@ -229,13 +229,17 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
     // the LDS histogram doubles as the block's list cursors in direct mode
     constexpr bool LDS_HIST = BIN == kBinCountLds || BIN == kBinDirect;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int hist_words = LDS_HIST ? ((G.ntiles + 3) & ~3) : 0;
+    // count mode packs two 16-bit counters per word (a block's chunk is < 65536 triangles);
+    // direct mode needs 32-bit cursors
+    const int hist_words = BIN == kBinDirect ? ((G.ntiles + 3) & ~3)
+                         : BIN == kBinCountLds ? ((((G.ntiles + 1) >> 1) + 3) & ~3) : 0;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw);
     float *sv = reinterpret_cast<float *>(smem_raw) + hist_words;
     float *sn = sv + kThreads * 9;
 
-    if (LDS_HIST) {
-        for (int i = threadIdx.x; i < G.ntiles; i += kThreads) hist[i] = 0;
+    __shared__ int tile_box[4];   // direct bins: tile bounding box of the batch (x0, x1, y0, y1)
+    if (BIN == kBinCountLds) {
+        for (int i = threadIdx.x; i < hist_words; i += kThreads) hist[i] = 0;
     }
     const int64_t c0 = (int64_t)blockIdx.x * chunk;
     const int64_t c1 = (c0 + chunk < T) ? (c0 + chunk) : T;
@@ -244,6 +248,9 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
         const int n = (int)((c1 - b0) < kThreads ? (c1 - b0) : kThreads);
         stage_in(tri_in + b0 * 9, sv, n * 9);
         stage_in(nrm + b0 * 9, sn, n * 9);
+        if (BIN == kBinDirect && threadIdx.x == 0) {
+            tile_box[0] = 0x7FFFFFFF; tile_box[1] = -1; tile_box[2] = 0x7FFFFFFF; tile_box[3] = -1;
+        }
         __syncthreads();
         uint2 r_keep = make_uint2(kNoTiles, 0);
         if ((int)threadIdx.x < n) {
@@ -273,37 +280,60 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
             }
             r_keep = r;
         }
-        // list lengths (pass A of the direct bins): LDS histogram or global counters
-        for_each_tile(r_keep, 0u, G.ntx, [&](int tile, uint32_t) {
-            if (LDS_HIST) atomicAdd(&hist[tile], 1u);
-            else atomicAdd(&count[tile], 1u);
-        });
-        __syncthreads();
-        if (PROJECT) stage_out(proj_out + b0 * 9, sv, n * 9);
         if (BIN == kBinDirect) {
-            // pass B: one global atomic per touched tile reserves a run of that tile's list;
-            // pass C: the block's entries take consecutive slots of the run (LDS cursors)
-            for (int i = threadIdx.x; i < G.ntiles; i += kThreads) {
-                const uint32_t c = hist[i];
-                if (c) hist[i] = atomicAdd(&count[i], c);
+            // A batch of consecutive triangles is a compact patch of the mesh: its lists touch
+            // a small rectangle of tiles.  Only that rectangle of the LDS histogram is zeroed,
+            // counted, reserved and reset, instead of all ntiles entries per pass.
+            int bx0 = 0x7FFFFFFF, bx1 = -1, by0 = 0x7FFFFFFF, by1 = -1;
+            if (r_keep.x != kNoTiles) {
+                bx0 = r_keep.x & 0xFFFF; bx1 = r_keep.x >> 16; by0 = r_keep.y & 0xFFFF; by1 = r_keep.y >> 16;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                bx0 = min(bx0, __shfl_xor(bx0, d, 64)); bx1 = max(bx1, __shfl_xor(bx1, d, 64));
+                by0 = min(by0, __shfl_xor(by0, d, 64)); by1 = max(by1, __shfl_xor(by1, d, 64));
+            }
+            if ((threadIdx.x & 63) == 0 && bx1 >= 0) {
+                atomicMin(&tile_box[0], bx0); atomicMax(&tile_box[1], bx1);
+                atomicMin(&tile_box[2], by0); atomicMax(&tile_box[3], by1);
             }
             __syncthreads();
-            {
-                for_each_tile(r_keep, (uint32_t)(b0 + threadIdx.x), G.ntx, [&](int tile, uint32_t id) {
-                    const uint32_t slot = atomicAdd(&hist[tile], 1u);
-                    if (slot < dcap) dlist[(size_t)tile * dcap + slot] = id;
-                    else atomicMax(&hdr[1], slot + 1);
-                });
+            const int tx_lo = tile_box[0], tx_hi = tile_box[1], ty_lo = tile_box[2], ty_hi = tile_box[3];
+            const int bw = tx_hi - tx_lo + 1, area = tx_hi < 0 ? 0 : bw * (ty_hi - ty_lo + 1);
+            auto box_tile = [&](int i) { const int dy = i / bw; return (ty_lo + dy) * G.ntx + tx_lo + (i - dy * bw); };
+            for (int i = threadIdx.x; i < area; i += kThreads) hist[box_tile(i)] = 0;
+            __syncthreads();
+            // pass A: this batch's entries per tile
+            for_each_tile(r_keep, 0u, G.ntx, [&](int tile, uint32_t) { atomicAdd(&hist[tile], 1u); });
+            __syncthreads();
+            if (PROJECT) stage_out(proj_out + b0 * 9, sv, n * 9);
+            // pass B: one global atomic per touched tile reserves a run of that tile's list
+            for (int i = threadIdx.x; i < area; i += kThreads) {
+                const int t = box_tile(i);
+                const uint32_t c = hist[t];
+                if (c) hist[t] = atomicAdd(&count[t], c);
             }
             __syncthreads();
-            // cursors back to zero for the block's next batch
-            for (int i = threadIdx.x; i < G.ntiles; i += kThreads) hist[i] = 0;
+            // pass C: the batch's entries take consecutive slots of the run (LDS cursors)
+            for_each_tile(r_keep, (uint32_t)(b0 + threadIdx.x), G.ntx, [&](int tile, uint32_t id) {
+                const uint32_t slot = atomicAdd(&hist[tile], 1u);
+                if (slot < dcap) dlist[(size_t)tile * dcap + slot] = id;
+                else atomicMax(&hdr[1], slot + 1);
+            });
+        } else {
+            // list lengths: LDS histogram or global counters
+            for_each_tile(r_keep, 0u, G.ntx, [&](int tile, uint32_t) {
+                if (LDS_HIST) atomicAdd(&hist[tile >> 1], (tile & 1) ? 0x10000u : 1u);
+                else atomicAdd(&count[tile], 1u);
+            });
+            __syncthreads();
+            if (PROJECT) stage_out(proj_out + b0 * 9, sv, n * 9);
         }
         __syncthreads();
     }
     if (BIN == kBinCountLds) {
         for (int i = threadIdx.x; i < G.ntiles; i += kThreads) {
-            const uint32_t c = hist[i];
+            const uint32_t c = (hist[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
             if (c) atomicAdd(&count[i], c);
         }
     }
@@ -381,14 +411,21 @@ __global__ __launch_bounds__(kThreads) void k_fill(const uint2 *__restrict__ tra
     const int64_t c0 = (int64_t)blockIdx.x * chunk;
     const int64_t c1 = (c0 + chunk < T) ? (c0 + chunk) : T;
     const uint2 none = make_uint2(kNoTiles, 0);
+    constexpr int U = 4;   // tile ranges in flight per thread: the loop is latency-bound
     if (LDS_HIST) {
         for (int i = threadIdx.x; i < G.ntiles; i += kThreads) cur[i] = 0;
         __syncthreads();
         // sweep 1: how many entries this block adds to each tile list
-        for (int64_t b0 = c0; b0 < c1; b0 += kThreads) {
-            const int64_t t = b0 + threadIdx.x;
-            for_each_tile(t < c1 ? trange[t] : none, 0u, G.ntx,
-                          [&](int tile, uint32_t) { atomicAdd(&cur[tile], 1u); });
+        for (int64_t b0 = c0; b0 < c1; b0 += (int64_t)U * kThreads) {
+            uint2 r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t t = b0 + (int64_t)u * kThreads + threadIdx.x;
+                r[u] = t < c1 ? trange[t] : none;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                for_each_tile(r[u], 0u, G.ntx, [&](int tile, uint32_t) { atomicAdd(&cur[tile], 1u); });
         }
         __syncthreads();
         // reserve a contiguous run in every touched list
@@ -398,14 +435,23 @@ __global__ __launch_bounds__(kThreads) void k_fill(const uint2 *__restrict__ tra
         }
         __syncthreads();
     }
-    for (int64_t b0 = c0; b0 < c1; b0 += kThreads) {
-        const int64_t t = b0 + threadIdx.x;
-        for_each_tile(t < c1 ? trange[t] : none, (uint32_t)t, G.ntx, [&](int tile, uint32_t id) {
-            uint32_t pos;
-            if (LDS_HIST) pos = atomicAdd(&cur[tile], 1u);
-            else pos = offs[tile] + atomicAdd(&cursor[tile], 1u);
-            if (pos < capacity) entries[pos] = id;
-        });
+    for (int64_t b0 = c0; b0 < c1; b0 += (int64_t)U * kThreads) {
+        uint2 r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t t = b0 + (int64_t)u * kThreads + threadIdx.x;
+            r[u] = t < c1 ? trange[t] : none;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t t = b0 + (int64_t)u * kThreads + threadIdx.x;
+            for_each_tile(r[u], (uint32_t)t, G.ntx, [&](int tile, uint32_t id) {
+                uint32_t pos;
+                if (LDS_HIST) pos = atomicAdd(&cur[tile], 1u);
+                else pos = offs[tile] + atomicAdd(&cursor[tile], 1u);
+                if (pos < capacity) entries[pos] = id;
+            });
+        }
     }
 }
 
@@ -508,8 +554,10 @@ __device__ unsigned long long *g_stamps = nullptr;
 #define CR_STAMP(slot) do { } while (0)
 #endif
 
+// 6 wavefronts per SIMD (<= 80 VGPRs): measured faster than the unconstrained 92-98 VGPR build
+// on every workload (r01 A/B, variants lb6/lb7/lb8); 7 costs more in spills than it gains.
 template <int TS, bool CLEAR>
-__global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ proj,
+__global__ __launch_bounds__(kThreads, 6) void k_raster(const float *__restrict__ proj,
                                                      const float *__restrict__ col,
                                                      const float *__restrict__ nrm,
                                                      const uint32_t *__restrict__ offs,
@@ -919,8 +967,9 @@ int grid_for(size_t items, int cap)
     return (int)b;
 }
 
-// LDS histogram of the tile lists fits next to the staging buffers up to this many tiles.
-constexpr int kMaxLdsHistTiles = 8192;  // 32 KiB histogram + 18 KiB staging < 64 KiB
+// LDS histograms up to this many tiles: k_setup packs 16-bit counters (32 KiB + 18 KiB of
+// staging), k_fill needs 32-bit cursors (64 KiB, the dynamic-LDS limit is raised for it).
+constexpr int kMaxLdsHistTiles = 16384;
 
 template <int TS>
 int run_tile_frame(crender_plan *plan, bool project, const float *d_tri, const float *d_col,
@@ -945,12 +994,20 @@ int run_tile_frame(crender_plan *plan, bool project, const float *d_tri, const f
         chunk = (chunk + kThreads - 1) / kThreads * kThreads;
         nblk = (T + chunk - 1) / chunk;
     };
-    const bool lds_hist = G.ntiles <= kMaxLdsHistTiles;
+    // block-private LDS histograms pay off when a block's chunk is dense in tiles; a small
+    // scene on a large tile grid would only zero and flush mostly empty histograms
+    const bool lds_hist = G.ntiles <= 4096 || (G.ntiles <= kMaxLdsHistTiles && T >= 16 * (int64_t)G.ntiles);
     if (T > 0) {
         int64_t nblk, chunk;
         chunking(2048, nblk, chunk);
         const int bin = direct ? kBinDirect : (lds_hist ? kBinCountLds : kBinCountGlobal);
-        const size_t hist_bytes = bin != kBinCountGlobal ? sizeof(uint32_t) * (size_t)((G.ntiles + 3) & ~3) : 0;
+        const size_t hist_bytes = bin == kBinDirect ? sizeof(uint32_t) * (size_t)((G.ntiles + 3) & ~3)
+                                : bin == kBinCountLds ? sizeof(uint32_t) * (size_t)((((G.ntiles + 1) >> 1) + 3) & ~3) : 0;
+        while (bin == kBinCountLds && chunk > 65280) {   // 16-bit block-local counters
+            nblk *= 2;
+            chunk = ((T + nblk - 1) / nblk + kThreads - 1) / kThreads * kThreads;
+            nblk = (T + chunk - 1) / chunk;
+        }
         const size_t setup_lds = hist_bytes + sizeof(float) * kThreads * 9 * 2;
 #define CR_SETUP(PROJ, BIN)                                                                          \
     hipLaunchKernelGGL((k_setup<TS, PROJ, BIN>), dim3((unsigned)nblk), dim3(kThreads), setup_lds, s, \
@@ -976,6 +1033,12 @@ int run_tile_frame(crender_plan *plan, bool project, const float *d_tri, const f
             int64_t nblk, chunk;
             chunking(1024, nblk, chunk);
             const size_t lds = lds_hist ? sizeof(uint32_t) * (size_t)G.ntiles : 0;
+            if (lds_hist && lds > 48 * 1024) {
+                static const hipError_t attr = hipFuncSetAttribute(
+                    reinterpret_cast<const void *>(&k_fill<true>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                if (attr != hipSuccess) return fail_hip(attr, "hipFuncSetAttribute(k_fill)");
+            }
             if (lds_hist)
                 hipLaunchKernelGGL((k_fill<true>), dim3((unsigned)nblk), dim3(kThreads), lds, s,
                                    plan->trange(), plan->offs(), plan->count(), plan->entries(),
