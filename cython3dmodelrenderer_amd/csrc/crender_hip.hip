@@ -212,8 +212,11 @@ CR_DEV void for_each_tile(uint2 r, uint32_t payload, int ntx, F f)
 //                                   store each triangle's tile range for k_fill (scan path);
 //   kBinDirect                      small scenes: append the triangle index straight into
 //                                   fixed-capacity per-tile lists, no k_scan / k_fill.
-enum { kBinCountLds = 0, kBinCountGlobal = 1, kBinDirect = 2 };
-constexpr int kDirectMaxTilesPerTriangle = 64;  // beyond this the scan path is used instead
+//   kBinDirectGlobal                the same on a large tile grid (few entries per tile, so
+//                                   the per-tile counters see little contention): one returning
+//                                   global atomic per entry, no LDS histogram.
+enum { kBinCountLds = 0, kBinCountGlobal = 1, kBinDirect = 2, kBinDirectGlobal = 3 };
+constexpr int kDirectMaxTilesPerTriangle = 1024;  // beyond this the scan path is used instead
 
 // dynamic LDS: [hist: ntiles u32 if kBinCountLds][verts: 256*9 f32][normals: 256*9 f32]
 template <int TS, bool PROJECT, int BIN>
@@ -270,8 +273,8 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
                 const TriXYZ t{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]};
                 r = tile_range<TS>(t, G);
             }
-            if (BIN != kBinDirect) trange[b0 + threadIdx.x] = r;
-            if (BIN == kBinDirect && r.x != kNoTiles) {
+            if (BIN != kBinDirect && BIN != kBinDirectGlobal) trange[b0 + threadIdx.x] = r;
+            if ((BIN == kBinDirect || BIN == kBinDirectGlobal) && r.x != kNoTiles) {
                 const int ntl = (int)((r.x >> 16) - (r.x & 0xFFFF) + 1) * (int)((r.y >> 16) - (r.y & 0xFFFF) + 1);
                 if (ntl > kDirectMaxTilesPerTriangle) {
                     atomicMax(&hdr[1], 0xFFFFFFFFu);  // sticky: this scene needs the scan path
@@ -317,6 +320,42 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
             // pass C: the batch's entries take consecutive slots of the run (LDS cursors)
             for_each_tile(r_keep, (uint32_t)(b0 + threadIdx.x), G.ntx, [&](int tile, uint32_t id) {
                 const uint32_t slot = atomicAdd(&hist[tile], 1u);
+                if (slot < dcap) dlist[(size_t)tile * dcap + slot] = id;
+                else atomicMax(&hdr[1], slot + 1);
+            });
+        } else if (BIN == kBinDirectGlobal) {
+            if (PROJECT) stage_out(proj_out + b0 * 9, sv, n * 9);
+            // A lane's returning atomics are independent of each other: issue them all, then
+            // store (a loop of "atomic, wait, store" would pay one memory round trip per tile).
+            {
+                const uint32_t id = (uint32_t)(b0 + threadIdx.x);
+                int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+                if (r_keep.x != kNoTiles) {
+                    tx0 = r_keep.x & 0xFFFF; tx1 = r_keep.x >> 16; ty0 = r_keep.y & 0xFFFF; ty1 = r_keep.y >> 16;
+                }
+                const int w = tx1 - tx0 + 1, cnt = w * (ty1 - ty0 + 1);
+                if (cnt <= kWideTiles) {
+                    uint32_t slot[kWideTiles];
+#pragma unroll
+                    for (int k = 0; k < kWideTiles; ++k) {
+                        const int dy = k / (w > 0 ? w : 1);
+                        const int tile = (ty0 + dy) * G.ntx + tx0 + (k - dy * w);
+                        slot[k] = k < cnt ? atomicAdd(&count[tile], 1u) : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < kWideTiles; ++k) {
+                        if (k < cnt) {
+                            const int dy = k / w;
+                            const int tile = (ty0 + dy) * G.ntx + tx0 + (k - dy * w);
+                            if (slot[k] < dcap) dlist[(size_t)tile * dcap + slot[k]] = id;
+                            else atomicMax(&hdr[1], slot[k] + 1);
+                        }
+                    }
+                    r_keep.x = kNoTiles;   // done; only wide ranges are left for the cooperative walk
+                }
+            }
+            for_each_tile(r_keep, (uint32_t)(b0 + threadIdx.x), G.ntx, [&](int tile, uint32_t id) {
+                const uint32_t slot = atomicAdd(&count[tile], 1u);
                 if (slot < dcap) dlist[(size_t)tile * dcap + slot] = id;
                 else atomicMax(&hdr[1], slot + 1);
             });
@@ -554,10 +593,11 @@ __device__ unsigned long long *g_stamps = nullptr;
 #define CR_STAMP(slot) do { } while (0)
 #endif
 
-// 6 wavefronts per SIMD (<= 80 VGPRs): measured faster than the unconstrained 92-98 VGPR build
-// on every workload (r01 A/B, variants lb6/lb7/lb8); 7 costs more in spills than it gains.
+// No occupancy bound is declared: capping at 80 VGPRs (6 wavefronts per SIMD) was 3-5 % faster
+// on the fill-heavy workloads but 5 % slower on T-Rex 1024^2, and its 32 B/lane of scratch shows
+// up as +5..+25 % WRITE_SIZE (r01 A/B, same box).  92-98 VGPRs, no scratch.
 template <int TS, bool CLEAR>
-__global__ __launch_bounds__(kThreads, 6) void k_raster(const float *__restrict__ proj,
+__global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ proj,
                                                      const float *__restrict__ col,
                                                      const float *__restrict__ nrm,
                                                      const uint32_t *__restrict__ offs,
@@ -905,8 +945,9 @@ struct Layout {
 // Direct bins are for small scenes (the README benchmark): one launch fewer than the
 // count / scan / fill path matters when a frame takes tens of microseconds.
 constexpr int64_t kDirectMaxTriangles = 1 << 16;
-constexpr int kDirectMaxTiles = 8192;   // the block-level cursors live in an LDS histogram
-constexpr int64_t kDirectCap = 1024;
+constexpr int kDirectLdsMaxTiles = 4096;    // up to here: block-level LDS cursors (kBinDirect)
+constexpr int kDirectMaxTiles = 1 << 16;    // beyond: count / scan / fill
+constexpr int64_t kDirectBinBytes = 64ll << 20;   // per-tile capacity = this budget / tiles, <= 1024
 
 bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int tile, Layout &L)
 {
@@ -929,7 +970,11 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
     L.off_trange = o;  o = align_up(o + sizeof(uint2) * (size_t)max_T);
     L.off_proj = o;    o = align_up(o + sizeof(float) * 9 * (size_t)max_T);
     L.off_entries = o; o = align_up(o + sizeof(uint32_t) * (size_t)cap);
-    L.direct_cap = (max_T <= kDirectMaxTriangles && L.g.ntiles <= kDirectMaxTiles) ? kDirectCap : 0;
+    L.direct_cap = 0;
+    if (max_T <= kDirectMaxTriangles && L.g.ntiles <= kDirectMaxTiles) {
+        L.direct_cap = kDirectBinBytes / 4 / L.g.ntiles;
+        if (L.direct_cap > 1024) L.direct_cap = 1024;
+    }
     L.off_direct = o;  o = align_up(o + sizeof(uint32_t) * (size_t)L.g.ntiles * (size_t)L.direct_cap);
     L.total = o;
     return true;
@@ -1000,7 +1045,8 @@ int run_tile_frame(crender_plan *plan, bool project, const float *d_tri, const f
     if (T > 0) {
         int64_t nblk, chunk;
         chunking(2048, nblk, chunk);
-        const int bin = direct ? kBinDirect : (lds_hist ? kBinCountLds : kBinCountGlobal);
+        const int bin = direct ? (G.ntiles <= kDirectLdsMaxTiles ? kBinDirect : kBinDirectGlobal)
+                               : (lds_hist ? kBinCountLds : kBinCountGlobal);
         const size_t hist_bytes = bin == kBinDirect ? sizeof(uint32_t) * (size_t)((G.ntiles + 3) & ~3)
                                 : bin == kBinCountLds ? sizeof(uint32_t) * (size_t)((((G.ntiles + 1) >> 1) + 3) & ~3) : 0;
         while (bin == kBinCountLds && chunk > 65280) {   // 16-bit block-local counters
@@ -1015,10 +1061,12 @@ int run_tile_frame(crender_plan *plan, bool project, const float *d_tri, const f
                        (uint32_t)L.direct_cap, plan->hdr(), T, chunk, P, G)
         if (project) {
             if (bin == kBinDirect) CR_SETUP(true, kBinDirect);
+            else if (bin == kBinDirectGlobal) CR_SETUP(true, kBinDirectGlobal);
             else if (bin == kBinCountLds) CR_SETUP(true, kBinCountLds);
             else CR_SETUP(true, kBinCountGlobal);
         } else {
             if (bin == kBinDirect) CR_SETUP(false, kBinDirect);
+            else if (bin == kBinDirectGlobal) CR_SETUP(false, kBinDirectGlobal);
             else if (bin == kBinCountLds) CR_SETUP(false, kBinCountLds);
             else CR_SETUP(false, kBinCountGlobal);
         }

@@ -57,7 +57,7 @@ def _as_device_f32(a, name, device):
 class AdvancedPixelBufferFiller:
     def __init__(self, h, w, fov=90.0, z_near=0.1, z_far=1000.0, n_threads=1, *,
                  device=None, tile=0, row_strip=None, track_winner=False, cache_inputs=True,
-                 bin_capacity=0):
+                 bin_capacity=0, direct_bins=True):
         self._lib = _capi.load()                      # raises if the HIP library is missing
         if not torch.cuda.is_available():
             raise _capi.CrenderError("AdvancedPixelBufferFiller needs a ROCm GPU (no CPU fallback)")
@@ -90,7 +90,7 @@ class AdvancedPixelBufferFiller:
         self._inputs = None            # (tri, col, nrm) device tensors of the last frame
         self._input_key = None
         self._last_flags = 0
-        self._extra_flags = 0
+        self._extra_flags = 0 if direct_bins else _capi.NO_DIRECT_BINS
         self._host = {}                # name -> numpy mirror handed out by a getter
         self._host_fresh = False       # mirrors equal the device buffers
         self._host_exposed = False     # a mirror was handed out and may have been edited

@@ -427,20 +427,40 @@ def test_filler_error_behaviour():
 
 
 def test_filler_recovers_from_bin_overflow(oracle):
+    """General binning path with far too small a list capacity: the getter notices, grows the
+    plan and renders the frame again."""
     from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
     rng = np.random.default_rng(21)
     tri, col, nrm = random_soup(rng, 400, 512, size_px=(150, 400), frac_backface=0.0)
-    filler = AdvancedPixelBufferFiller(512, 512, fov=45, tile=32, bin_capacity=500)
+    filler = AdvancedPixelBufferFiller(512, 512, fov=45, tile=32, bin_capacity=500, direct_bins=False)
     filler.render_arrays(tri, col, nrm)
     need, cap = filler.bin_usage()
-    assert need > cap                           # this frame dropped fragments (direct bins) ...
+    assert cap == 500 and need > cap            # this frame dropped fragments ...
     f = oracle.OracleFiller(512, 512, fov=45)
     f.render_arrays(tri, col, nrm)
-    # ... the getter falls back to the general path, finds 500 entries too few, grows, redoes it
-    assert_bit_equal(filler.get_z_buffer(), f.z_buffer, "z")
+    assert_bit_equal(filler.get_z_buffer(), f.z_buffer, "z")   # ... the getter grows and redoes it
     assert_bit_equal(filler.get_color_buffer(), f.color_buffer, "colour")
     need2, cap2 = filler.bin_usage()
-    assert cap2 > 500 and need2 <= cap2
+    assert need2 == need and cap2 >= need
+
+
+def test_filler_recovers_from_direct_bin_overflow(oracle):
+    """Small-scene direct bins hold 1024 entries per tile; 3000 triangles stacked in one tile
+    overflow them: the filler switches to the general path and the result is exact."""
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    rng = np.random.default_rng(22)
+    tri, col, nrm = random_soup(rng, 5000, 256, size_px=(2, 6), frac_backface=0.0, margin=-0.97)
+    filler = AdvancedPixelBufferFiller(256, 256, fov=45, tile=32)
+    filler.render_arrays(tri, col, nrm)
+    need, cap = filler.bin_usage()
+    assert cap == 1024 and need > cap
+    f = oracle.OracleFiller(256, 256, fov=45)
+    f.render_arrays(tri, col, nrm)
+    assert_bit_equal(filler.get_z_buffer(), f.z_buffer, "z")
+    assert_bit_equal(filler.get_color_buffer(), f.color_buffer, "colour")
+    assert_bit_equal(filler.get_normals_buffer(), f.normals_buffer, "normal")
+    need2, cap2 = filler.bin_usage()
+    assert need2 <= cap2 and cap2 != 1024       # general path now
 
 
 def test_renderer_with_illumination(oracle):
