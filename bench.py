@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--max-triangles", type=int, default=-1,
                     help="experiment knob: keep only the first N triangles (0 = pure clear)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not overlap the next frame's bin pass with this frame's raster pass")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
     args = ap.parse_args()
 
@@ -112,11 +114,12 @@ def main():
     T = int(tri.shape[0])
     y0, y1 = D.strip_rows(H, world, rank)
     filler = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile,
-                                       row_strip=(y0, y1) if world > 1 else None)
+                                       row_strip=(y0, y1) if world > 1 else None,
+                                       pipeline=not args.no_pipeline)
     planes = [filler.z_buffer, filler.color_buffer, filler.normals_buffer]
 
-    def step():
-        filler.render_frame()
+    def step(pipelined=True):
+        filler.render_frame(pipelined=pipelined)
         if world > 1 and not args.no_gather:
             D.all_gather_strips(planes, H, rank, world)
 
@@ -139,21 +142,26 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    need, cap = filler.bin_usage()
-    assert need <= cap, "bin lists overflowed inside the timed region"
+    assert not (filler._pipe is not None and filler._pipe.overflowed(filler)), \
+        "bin lists overflowed inside the timed region"
 
     # ---- per-kernel durations: the same K steps again with HIP events on the frame's stream
-    # around the binning passes and around the raster kernel.  Kept out of the timed region
+    # around the binning passes and around the raster kernel (single stream, not pipelined, so
+    # each kernel's duration is its own).  Kept out of the timed region
     # above because the three event records cost ~11 us per frame on a ~35 us frame (measured:
     # scripts/hostoverhead.py vs this loop); the events loop's own frame time is reported too.
+    step(pipelined=False)            # also makes sure the single-stream plan exists
+    barrier()
     filler.timing_begin(args.steps)
     barrier()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(pipelined=False)
     barrier()
     elapsed_events = time.perf_counter() - t1
     n_timed, bin_ms, raster_ms = filler.timing_end()
+    need, cap = filler.bin_usage()
+    assert need <= cap, "bin lists overflowed inside the timing pass"
 
     if world > 1:
         t = torch.tensor([elapsed, raster_ms, bin_ms], dtype=torch.float64, device=device)
@@ -178,6 +186,7 @@ def main():
             "config": {"workload": args.workload, "triangles": T, "height": H, "width": W,
                        "fov": fov, "row_strips": world, "tile": filler.tile or "auto",
                        "frame": "clear + project + rasterize, model resident in HBM",
+                       "pipelined": bool(not args.no_pipeline),
                        "all_gather": bool(world > 1 and not args.no_gather)},
             "mtris_per_sec": T * fps / 1e6,
             "frame_algorithmic_bytes": algorithmic_bytes(T, H, W),

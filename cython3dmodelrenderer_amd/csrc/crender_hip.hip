@@ -69,6 +69,7 @@ struct Geom {
     int y0, y1;    // strip rows
     int ntx, nty;  // tiles across / down the strip
     int ntiles;
+    int tile_stride;  // odd-ish multiplier coprime to ntiles: scatters the dispatch order
 };
 
 ProjConst make_proj(const float *P16, int w, int h)
@@ -610,7 +611,13 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ p
     __shared__ unsigned long long key[TS * TS];
     __shared__ WorkQueue q;
 
-    const int tile = (dbg & 8) ? xcd_band_tile(blockIdx.x, G.ntiles) : (int)blockIdx.x;
+    int tile = (dbg & 8) ? xcd_band_tile(blockIdx.x, G.ntiles) : (int)blockIdx.x;
+    // Large grids: scatter the dispatch order (block b -> tile b * stride mod ntiles) so that a
+    // band of covered tiles is spread over the whole launch instead of arriving together
+    // (T-Rex 8192^2: 0.446 -> 0.402 ms).  Small grids are faster in raster order
+    // (T-Rex 1024^2: 24.7 vs 29.1 us), so the scatter starts at 32768 tiles.
+    if ((G.ntiles >= 32768) != ((dbg & 256) != 0))
+        tile = (int)(((unsigned long long)blockIdx.x * (unsigned)G.tile_stride) % (unsigned)G.ntiles);
     const int tx = tile % G.ntx, ty = tile / G.ntx;
     const int X0 = tx * TS, Y0 = G.y0 + ty * TS;
     const int X1 = (X0 + TS < G.W) ? (X0 + TS) : G.W;
@@ -959,6 +966,12 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
     L.g.ntx = (W + L.ts - 1) / L.ts;
     L.g.nty = (y1 - y0 + L.ts - 1) / L.ts;
     L.g.ntiles = L.g.ntx * L.g.nty;
+    {   // a stride near ntiles / golden ratio, made coprime to ntiles
+        auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+        int k = (int)(L.g.ntiles * 0.6180339887) | 1;
+        while (k > 1 && gcd(k, L.g.ntiles) != 1) k += 2;
+        L.g.tile_stride = k < 1 ? 1 : k;
+    }
     L.max_T = max_T;
     if (cap <= 0) cap = 4 * max_T + 4 * (int64_t)L.g.ntiles + 65536;
     if (cap > 0xFFFFFFF0ll) cap = 0xFFFFFFF0ll;
@@ -991,6 +1004,7 @@ struct crender_plan {
     int timed_frames = 0;
     bool direct_ok = true;        // cleared once a frame overflowed the direct bins
     bool last_frame_direct = false;
+    int64_t last_T = -1;          // triangle count of the last bin pass (crender_draw must match)
     uint32_t *direct() const { return reinterpret_cast<uint32_t *>(ws + L.off_direct); }
     bool timing() const { return !events.empty() && (size_t)(timed_frames + 1) * 3 <= events.size(); }
     hipEvent_t ev(int k) const { return events[(size_t)timed_frames * 3 + k]; }
@@ -1000,6 +1014,20 @@ struct crender_plan {
     uint2 *trange() const { return reinterpret_cast<uint2 *>(ws + L.off_trange); }
     float *proj() const { return reinterpret_cast<float *>(ws + L.off_proj); }
     uint32_t *entries() const { return reinterpret_cast<uint32_t *>(ws + L.off_entries); }
+};
+
+// Double-buffered frames: bin pass of frame i+1 on an auxiliary stream overlapping the raster
+// pass of frame i on the caller's stream (crender_pipeline_*).
+struct crender_pipeline {
+    crender_plan *plan[2];
+    hipStream_t aux = nullptr;
+    hipEvent_t prep_done[2] = {nullptr, nullptr};
+    hipEvent_t draw_done[2] = {nullptr, nullptr};
+    hipEvent_t mark = nullptr;
+    bool drawn[2] = {false, false};
+    uint64_t n = 0;
+    const void *last_tri = nullptr, *last_nrm = nullptr;
+    int64_t last_T = -1;
 };
 
 namespace {
@@ -1016,20 +1044,18 @@ int grid_for(size_t items, int cap)
 // staging), k_fill needs 32-bit cursors (64 KiB, the dynamic-LDS limit is raised for it).
 constexpr int kMaxLdsHistTiles = 16384;
 
+// Frame = bin pass (K1 + binning into the plan) + raster pass (K2 from the plan's bins).
 template <int TS>
-int run_tile_frame(crender_plan *plan, bool project, const float *d_tri, const float *d_col,
-                   const float *d_nrm, int64_t T, const ProjConst &P, float *d_z, float *d_color,
-                   float *d_normal, int32_t *d_winner, unsigned flags, hipStream_t s)
+int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const float *d_nrm, int64_t T,
+                 const ProjConst &P, unsigned flags, hipStream_t s)
 {
     const Layout &L = plan->L;
     const Geom G = L.g;
-    const float *proj = project ? plan->proj() : d_tri;
-    const bool timing = plan->timing();
     static const int dbg = std::getenv("CRENDER_DEBUG") ? std::atoi(std::getenv("CRENDER_DEBUG")) : 0;
     const bool direct = L.direct_cap > 0 && plan->direct_ok && !(flags & CRENDER_NO_DIRECT_BINS) &&
                         !(dbg & 16);
     plan->last_frame_direct = direct;
-    if (timing) CR_HIP(hipEventRecord(plan->ev(0), s));
+    plan->last_T = T;
 
     // contiguous chunk of triangles per block, a multiple of the block size
     auto chunking = [T](int64_t max_blocks, int64_t &nblk, int64_t &chunk) {
@@ -1098,7 +1124,18 @@ int run_tile_frame(crender_plan *plan, bool project, const float *d_tri, const f
             CR_LAUNCH_CHECK("k_fill");
         }
     }
-    if (timing) CR_HIP(hipEventRecord(plan->ev(1), s));
+    return CRENDER_OK;
+}
+
+template <int TS>
+int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, const float *d_nrm,
+                    float *d_z, float *d_color, float *d_normal, int32_t *d_winner, unsigned flags,
+                    hipStream_t s)
+{
+    const Layout &L = plan->L;
+    const Geom G = L.g;
+    static const int dbg = std::getenv("CRENDER_DEBUG") ? std::atoi(std::getenv("CRENDER_DEBUG")) : 0;
+    const bool direct = plan->last_frame_direct;
     const uint32_t *offs = direct ? nullptr : plan->offs();
     const uint32_t *list = direct ? plan->direct() : plan->entries();
     const uint32_t cap = direct ? (uint32_t)L.direct_cap : (uint32_t)L.capacity;
@@ -1111,11 +1148,40 @@ int run_tile_frame(crender_plan *plan, bool project, const float *d_tri, const f
                            d_col, d_nrm, offs, plan->count(), list, cap, d_z, d_color, d_normal,
                            d_winner, G, dbg);
     CR_LAUNCH_CHECK("k_raster");
-    if (timing) {
-        CR_HIP(hipEventRecord(plan->ev(2), s));
-        plan->timed_frames++;
-    }
     return CRENDER_OK;
+}
+
+#define CR_BY_TILE(call16, call32, call64) \
+    (plan->L.ts == 16 ? (call16) : plan->L.ts == 32 ? (call32) : (call64))
+
+int bin_pass(crender_plan *plan, bool project, const float *d_tri, const float *d_nrm, int64_t T,
+             const float *P16, unsigned flags, void *stream)
+{
+    if (!plan) return fail(CRENDER_EINVAL, "null plan");
+    if (T < 0 || T > plan->L.max_T) return fail(CRENDER_EINVAL, "T exceeds the plan's max_T");
+    if (T > 0 && (!d_tri || !d_nrm)) return fail(CRENDER_EINVAL, "null triangle array");
+    if (project && !P16) return fail(CRENDER_EINVAL, "null projection matrix");
+    ProjConst P;
+    std::memset(&P, 0, sizeof P);
+    if (project) P = make_proj(P16, plan->L.g.W, plan->L.g.H);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return CR_BY_TILE(run_bin_pass<16>(plan, project, d_tri, d_nrm, T, P, flags, s),
+                      run_bin_pass<32>(plan, project, d_tri, d_nrm, T, P, flags, s),
+                      run_bin_pass<64>(plan, project, d_tri, d_nrm, T, P, flags, s));
+}
+
+int raster_pass(crender_plan *plan, const float *proj, const float *d_col, const float *d_nrm, int64_t T,
+                float *d_z, float *d_color, float *d_normal, int32_t *d_winner, unsigned flags,
+                void *stream)
+{
+    if (!plan) return fail(CRENDER_EINVAL, "null plan");
+    if (T != plan->last_T) return fail(CRENDER_EINVAL, "T differs from the prepared frame's");
+    if (!d_z || !d_color || !d_normal) return fail(CRENDER_EINVAL, "null framebuffer pointer");
+    if (T > 0 && (!proj || !d_col || !d_nrm)) return fail(CRENDER_EINVAL, "null triangle array");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return CR_BY_TILE(run_raster_pass<16>(plan, proj, d_col, d_nrm, d_z, d_color, d_normal, d_winner, flags, s),
+                      run_raster_pass<32>(plan, proj, d_col, d_nrm, d_z, d_color, d_normal, d_winner, flags, s),
+                      run_raster_pass<64>(plan, proj, d_col, d_nrm, d_z, d_color, d_normal, d_winner, flags, s));
 }
 
 int tile_frame(crender_plan *plan, bool project, const float *d_tri, const float *d_col,
@@ -1123,22 +1189,22 @@ int tile_frame(crender_plan *plan, bool project, const float *d_tri, const float
                float *d_normal, int32_t *d_winner, unsigned flags, void *stream)
 {
     if (!plan) return fail(CRENDER_EINVAL, "null plan");
-    if (T < 0 || T > plan->L.max_T) return fail(CRENDER_EINVAL, "T exceeds the plan's max_T");
     if (!d_z || !d_color || !d_normal) return fail(CRENDER_EINVAL, "null framebuffer pointer");
-    if (T > 0 && (!d_tri || !d_col || !d_nrm)) return fail(CRENDER_EINVAL, "null triangle array");
-    if (project && !P16) return fail(CRENDER_EINVAL, "null projection matrix");
-    ProjConst P;
-    std::memset(&P, 0, sizeof P);
-    if (project) P = make_proj(P16, plan->L.g.W, plan->L.g.H);
+    if (T > 0 && !d_col) return fail(CRENDER_EINVAL, "null triangle array");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (plan->L.ts == 16)
-        return run_tile_frame<16>(plan, project, d_tri, d_col, d_nrm, T, P, d_z, d_color, d_normal,
-                                  d_winner, flags, s);
-    if (plan->L.ts == 32)
-        return run_tile_frame<32>(plan, project, d_tri, d_col, d_nrm, T, P, d_z, d_color, d_normal,
-                                  d_winner, flags, s);
-    return run_tile_frame<64>(plan, project, d_tri, d_col, d_nrm, T, P, d_z, d_color, d_normal,
-                              d_winner, flags, s);
+    const bool timing = plan->timing();
+    if (timing) CR_HIP(hipEventRecord(plan->ev(0), s));
+    int rc = bin_pass(plan, project, d_tri, d_nrm, T, P16, flags, stream);
+    if (rc != CRENDER_OK) return rc;
+    if (timing) CR_HIP(hipEventRecord(plan->ev(1), s));
+    rc = raster_pass(plan, project ? plan->proj() : d_tri, d_col, d_nrm, T, d_z, d_color, d_normal,
+                     d_winner, flags, stream);
+    if (rc != CRENDER_OK) return rc;
+    if (timing) {
+        CR_HIP(hipEventRecord(plan->ev(2), s));
+        plan->timed_frames++;
+    }
+    return CRENDER_OK;
 }
 
 }  // namespace
@@ -1314,6 +1380,21 @@ int crender_raster(crender_plan *plan, const float *d_tri_proj, const float *d_c
                       d_winner, flags, stream);
 }
 
+int crender_prepare(crender_plan *plan, const float *d_tri, const float *d_nrm, int64_t T,
+                    const float *P16, unsigned flags, void *stream)
+{
+    return bin_pass(plan, P16 != nullptr, d_tri, d_nrm, T, P16, flags, stream);
+}
+
+int crender_draw(crender_plan *plan, const float *d_tri_proj, const float *d_col, const float *d_nrm,
+                 int64_t T, float *d_z, float *d_color, float *d_normal, int32_t *d_winner,
+                 unsigned flags, void *stream)
+{
+    if (!plan) return fail(CRENDER_EINVAL, "null plan");
+    return raster_pass(plan, d_tri_proj ? d_tri_proj : plan->proj(), d_col, d_nrm, T, d_z, d_color,
+                       d_normal, d_winner, flags, stream);
+}
+
 int crender_render_model(crender_plan *plan, const float *d_tri, const float *d_col, const float *d_nrm,
                          int64_t T, const float *P16, float *d_z, float *d_color, float *d_normal,
                          int32_t *d_winner, unsigned flags, void *stream)
@@ -1341,6 +1422,81 @@ int crender_selfcheck_division(const float *d_num, const float *d_den, float *d_
     hipLaunchKernelGGL(k_divcheck, dim3(grid_for((size_t)n, 8192)), dim3(kThreads), 0,
                        static_cast<hipStream_t>(stream), d_num, d_den, d_out_tail, d_out_div, (size_t)n);
     CR_LAUNCH_CHECK("k_divcheck");
+    return CRENDER_OK;
+}
+
+int crender_pipeline_create(crender_pipeline **out, crender_plan *plan_a, crender_plan *plan_b)
+{
+    if (!out || !plan_a || !plan_b || plan_a == plan_b)
+        return fail(CRENDER_EINVAL, "crender_pipeline_create: need two distinct plans");
+    *out = nullptr;
+    crender_pipeline *p = new (std::nothrow) crender_pipeline();
+    if (!p) return fail(CRENDER_ENOMEM, "crender_pipeline_create: host allocation failed");
+    p->plan[0] = plan_a;
+    p->plan[1] = plan_b;
+    hipError_t e = hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipEventCreateWithFlags(&p->prep_done[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->draw_done[k], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->mark, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        crender_pipeline_destroy(p);
+        return fail_hip(e, "crender_pipeline_create");
+    }
+    *out = p;
+    return CRENDER_OK;
+}
+
+void crender_pipeline_destroy(crender_pipeline *p)
+{
+    if (!p) return;
+    if (p->aux) (void)hipStreamSynchronize(p->aux);
+    for (int k = 0; k < 2; ++k) {
+        if (p->prep_done[k]) (void)hipEventDestroy(p->prep_done[k]);
+        if (p->draw_done[k]) (void)hipEventDestroy(p->draw_done[k]);
+    }
+    if (p->mark) (void)hipEventDestroy(p->mark);
+    if (p->aux) (void)hipStreamDestroy(p->aux);
+    delete p;
+}
+
+int crender_pipeline_frame(crender_pipeline *p, const float *d_tri, const float *d_col,
+                           const float *d_nrm, int64_t T, const float *P16, float *d_z, float *d_color,
+                           float *d_normal, int32_t *d_winner, unsigned flags, void *stream)
+{
+    if (!p) return fail(CRENDER_EINVAL, "null pipeline");
+    hipStream_t main_s = static_cast<hipStream_t>(stream);
+    if (d_tri != p->last_tri || d_nrm != p->last_nrm || T != p->last_T) {
+        // new inputs: whatever produced them was enqueued on the caller's stream
+        CR_HIP(hipEventRecord(p->mark, main_s));
+        CR_HIP(hipStreamWaitEvent(p->aux, p->mark, 0));
+        p->last_tri = d_tri; p->last_nrm = d_nrm; p->last_T = T;
+    }
+    const int k = (int)(p->n & 1);
+    p->n++;
+    if (p->drawn[k]) CR_HIP(hipStreamWaitEvent(p->aux, p->draw_done[k], 0));  // plan k's bins are free
+    int rc = crender_prepare(p->plan[k], d_tri, d_nrm, T, P16, flags, p->aux);
+    if (rc != CRENDER_OK) return rc;
+    CR_HIP(hipEventRecord(p->prep_done[k], p->aux));
+    CR_HIP(hipStreamWaitEvent(main_s, p->prep_done[k], 0));
+    rc = crender_draw(p->plan[k], P16 ? nullptr : d_tri, d_col, d_nrm, T, d_z, d_color, d_normal,
+                      d_winner, flags, stream);
+    if (rc != CRENDER_OK) return rc;
+    CR_HIP(hipEventRecord(p->draw_done[k], main_s));
+    p->drawn[k] = true;
+    return CRENDER_OK;
+}
+
+int crender_pipeline_join(crender_pipeline *p, void *stream)
+{
+    if (!p) return fail(CRENDER_EINVAL, "null pipeline");
+    // the aux stream only ever runs bin passes whose raster passes are already ordered on the
+    // caller's stream, so waiting for the last prepare is enough
+    CR_HIP(hipEventRecord(p->mark, p->aux));
+    CR_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->mark, 0));
+    p->last_tri = p->last_nrm = nullptr;   // next frame re-synchronises the aux stream
+    p->last_T = -1;
     return CRENDER_OK;
 }
 

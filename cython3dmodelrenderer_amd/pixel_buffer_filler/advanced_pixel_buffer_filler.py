@@ -54,10 +54,76 @@ def _as_device_f32(a, name, device):
     return t
 
 
+class _FramePipeline:
+    """Double-buffered frames for ``render_frame``: the bin pass of frame i+1 overlaps the
+    raster pass of frame i (``crender_pipeline_*``: two plans, a second stream and the events
+    between them live in the library, so a frame is ONE call from Python).  Every frame still
+    does all of its work; only consecutive frames overlap."""
+
+    def __init__(self, filler, T):
+        self.lib = filler._lib
+        self.device = filler.device
+        self.plans, self.workspaces = [], []
+        for _ in range(2):
+            nbytes = self.lib.crender_plan_workspace_bytes(filler.h, filler.w, filler.y0, filler.y1,
+                                                           max(int(T), 1), filler._bin_request, filler.tile)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            plan = C.c_void_p()
+            _capi.check(self.lib.crender_plan_create(C.byref(plan), filler.h, filler.w, filler.y0,
+                                                     filler.y1, max(int(T), 1), filler._bin_request,
+                                                     filler.tile, ws.data_ptr(), nbytes, filler._stream()),
+                        "crender_plan_create")
+            self.plans.append(plan)
+            self.workspaces.append(ws)
+        self.max_T = max(int(T), 1)
+        self.handle = C.c_void_p()
+        _capi.check(self.lib.crender_pipeline_create(C.byref(self.handle), self.plans[0], self.plans[1]),
+                    "crender_pipeline_create")
+        self.n = 0
+        self._args = None
+
+    def close(self):
+        if self.handle:
+            self.lib.crender_pipeline_destroy(self.handle)
+            self.handle = C.c_void_p()
+        for plan in self.plans:
+            self.lib.crender_plan_destroy(plan)
+        self.plans = []
+
+    def frame(self, filler):
+        if self._args is None or self._args[0] is not filler._inputs:
+            tri, col, nrm = filler._inputs
+            # everything but the stream is fixed while the resident model is: build the
+            # ctypes argument tuple once
+            self._args = (filler._inputs,
+                          (self.handle, tri.data_ptr(), col.data_ptr(), nrm.data_ptr(), tri.shape[0],
+                           filler._P, filler.z_buffer.data_ptr(), filler.color_buffer.data_ptr(),
+                           filler.normals_buffer.data_ptr(), filler._win_ptr(),
+                           _capi.FUSED_CLEAR | filler._extra_flags))
+        rc = self.lib.crender_pipeline_frame(*self._args[1], torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            _capi.check(rc, "crender_pipeline_frame")
+        self.n += 1
+
+    def join(self, filler):
+        _capi.check(self.lib.crender_pipeline_join(self.handle, filler._stream()), "crender_pipeline_join")
+
+    def overflowed(self, filler):
+        """Synchronising check of both plans' bin lists."""
+        self.join(filler)
+        for plan in self.plans:
+            need, cap = C.c_int64(), C.c_int64()
+            _capi.check(self.lib.crender_plan_last_bin_usage(plan, filler._stream(), C.byref(need),
+                                                             C.byref(cap)), "crender_plan_last_bin_usage")
+            if need.value > cap.value:
+                return True
+        return False
+
+
 class AdvancedPixelBufferFiller:
     def __init__(self, h, w, fov=90.0, z_near=0.1, z_far=1000.0, n_threads=1, *,
                  device=None, tile=0, row_strip=None, track_winner=False, cache_inputs=True,
-                 bin_capacity=0, direct_bins=True):
+                 bin_capacity=0, direct_bins=True, pipeline=False):
         self._lib = _capi.load()                      # raises if the HIP library is missing
         if not torch.cuda.is_available():
             raise _capi.CrenderError("AdvancedPixelBufferFiller needs a ROCm GPU (no CPU fallback)")
@@ -94,10 +160,15 @@ class AdvancedPixelBufferFiller:
         self._host = {}                # name -> numpy mirror handed out by a getter
         self._host_fresh = False       # mirrors equal the device buffers
         self._host_exposed = False     # a mirror was handed out and may have been edited
+        self._pipeline = bool(pipeline)  # render_frame(): overlap consecutive frames (see _FramePipeline)
+        self._pipe = None
 
     # ------------------------------------------------------------------ plumbing --
     def __del__(self):
         try:
+            if getattr(self, "_pipe", None):
+                self._pipe.close()
+                self._pipe = None
             if getattr(self, "_plan", None):
                 self._lib.crender_plan_destroy(self._plan)
                 self._plan = C.c_void_p()
@@ -163,6 +234,15 @@ class AdvancedPixelBufferFiller:
         """Synchronise; if the last frame overflowed its bin lists, grow them and redo it.
         Re-rendering is exact: the result is a per-pixel minimum over the prior value and
         all fragments, so fragments that already landed change nothing."""
+        if self._pipe is not None and self._pipe.n > 0:
+            if self._pipe.overflowed(self):
+                # rare: leave pipelining for good and redo the frame on the plain path
+                self._pipe.close()
+                self._pipe = None
+                self._pipeline = False
+                self._launch(_capi.FUSED_CLEAR)
+            else:
+                self._pipe.n = 0
         if not self._plan or self._inputs is None:
             torch.cuda.current_stream(self.device).synchronize()
             return
@@ -222,11 +302,28 @@ class AdvancedPixelBufferFiller:
             self._push_host_edits()
         self._launch(_capi.FUSED_CLEAR if clear else 0)
 
-    def render_frame(self):
+    def render_frame(self, pipelined=None):
         """One benchmark frame: clear + project + rasterize the resident model
         (SURVEY.md section 8d 'one frame').  Inputs must have been set by a previous
-        render_model / render_arrays call."""
-        self._launch(_capi.FUSED_CLEAR)
+        render_model / render_arrays call.  With ``pipeline=True`` (constructor) consecutive
+        frames overlap: the next frame's projection + binning runs on a second stream while
+        this frame rasterizes."""
+        use_pipe = self._pipeline if pipelined is None else (pipelined and self._pipeline)
+        if not use_pipe:
+            if self._pipe is not None and self._pipe.n > 0:
+                # plain frames after pipelined ones: let the pipeline's own stream drain first
+                self._pipe.join(self)
+                self._pipe.n = 0
+            self._launch(_capi.FUSED_CLEAR)
+            return
+        T = self._inputs[0].shape[0]
+        if self._pipe is None or T > self._pipe.max_T:
+            if self._pipe is not None:
+                torch.cuda.synchronize(self.device)
+                self._pipe.close()
+            self._pipe = _FramePipeline(self, T)
+        self._pipe.frame(self)
+        self._host_fresh = False
 
     def clear(self):
         """Back to the state __cinit__ leaves (.pyx:65-67)."""

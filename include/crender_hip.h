@@ -130,6 +130,36 @@ CRENDER_API int crender_render_model(crender_plan *plan, const float *d_tri, con
                          float *d_z, float *d_color, float *d_normal, int32_t *d_winner,
                          unsigned flags, void *stream);
 
+/* crender_render_model in two halves, so that a caller can overlap the first half of the
+ * next frame with the second half of the current one on another stream (two plans, double
+ * buffering; cython3dmodelrenderer_amd's filler does this in `pipeline` mode):
+ *   crender_prepare  K1 + binning into the plan.  P16 == NULL: d_tri is already projected.
+ *   crender_draw     K2 from the plan's bins.  d_tri_proj == NULL: use the vertices
+ *                    crender_prepare projected into the plan; T must equal the prepared T.
+ * The caller orders the two calls (same stream, or an event between streams) and must not
+ * prepare into a plan whose previous crender_draw has not finished. */
+CRENDER_API int crender_prepare(crender_plan *plan, const float *d_tri, const float *d_nrm, int64_t T,
+                    const float *P16, unsigned flags, void *stream);
+CRENDER_API int crender_draw(crender_plan *plan, const float *d_tri_proj, const float *d_col,
+                 const float *d_nrm, int64_t T, float *d_z, float *d_color, float *d_normal,
+                 int32_t *d_winner, unsigned flags, void *stream);
+
+/* The double buffering above, ready-made: one call per frame.  Frame i's crender_draw runs
+ * on `stream`; frame i+1's crender_prepare runs on a stream the pipeline owns, into the other
+ * plan, ordered by events.  Results are those of crender_render_model with the same
+ * arguments.  If the input pointers or T change, the pipeline first lets its stream catch
+ * up with `stream`; if inputs are overwritten IN PLACE, call crender_pipeline_join first.
+ * crender_pipeline_join makes `stream` wait for the pipeline's own stream (before using
+ * the plans directly or destroying them).  Bin-list overflow is queried per plan as usual. */
+typedef struct crender_pipeline crender_pipeline;
+CRENDER_API int crender_pipeline_create(crender_pipeline **out, crender_plan *plan_a, crender_plan *plan_b);
+CRENDER_API void crender_pipeline_destroy(crender_pipeline *pipeline);
+CRENDER_API int crender_pipeline_frame(crender_pipeline *pipeline, const float *d_tri, const float *d_col,
+                           const float *d_nrm, int64_t T, const float *P16,
+                           float *d_z, float *d_color, float *d_normal, int32_t *d_winner,
+                           unsigned flags, void *stream);
+CRENDER_API int crender_pipeline_join(crender_pipeline *pipeline, void *stream);
+
 /* Same contract as crender_raster, computed a second, independent way: one wavefront
  * per triangle, 64-bit global atomics on a packed (z, index) key plane, then a
  * per-pixel resolve.  Needs no plan; d_keys is caller-owned scratch of

@@ -463,6 +463,32 @@ def test_filler_recovers_from_direct_bin_overflow(oracle):
     assert need2 <= cap2 and cap2 != 1024       # general path now
 
 
+def test_pipelined_frames_are_exact(oracle):
+    """render_frame in pipeline mode overlaps the next frame's bin pass with this frame's raster
+    pass (two plans, two streams).  Whatever the interleaving, the buffers after frame N are
+    frame N's: checked after bursts of frames and after switching the resident model mid-stream."""
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    trex = scene("trex_inputs.npz")
+    cube = scene("cube_inputs.npz")
+    rng = np.random.default_rng(4)
+    soup = random_soup(rng, 20000, 300, size_px=(1, 30))
+    H, W = 300, 420
+    filler = AdvancedPixelBufferFiller(H, W, fov=45, pipeline=True, track_winner=True)
+    for model, bursts in ((trex, (1, 2, 7)), (soup, (3, 1)), (cube, (2,)), (trex, (5,))):
+        f = oracle.OracleFiller(H, W, fov=45)
+        f.render_arrays(*model)
+        filler.render_arrays(*model, clear=True)       # upload; plain (non-pipelined) frame
+        for burst in bursts:
+            for _ in range(burst):
+                filler.render_frame()
+            assert_bit_equal(filler.get_z_buffer(), f.z_buffer, "z")
+            assert_bit_equal(filler.get_color_buffer(), f.color_buffer, "colour")
+            assert_bit_equal(filler.get_normals_buffer(), f.normals_buffer, "normal")
+            assert_bit_equal(filler.get_winner_tensor().cpu().numpy(), f.winner, "winner")
+        filler.render_frame(pipelined=False)            # mixing plain frames in is fine too
+        assert_bit_equal(filler.get_z_buffer(), f.z_buffer, "z after a plain frame")
+
+
 def test_renderer_with_illumination(oracle):
     from cython3dmodelrenderer_amd import Renderer
     from cython3dmodelrenderer_amd.illumination import GuroIllumination
