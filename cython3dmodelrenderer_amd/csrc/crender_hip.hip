@@ -641,6 +641,24 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ p
     }
     if (dbg & 1) end = beg;   // ablation: no coverage work
 
+    if (beg == end) {
+        // nothing to rasterize here: the tile keeps its content, or (fused clear) becomes
+        // background — no key plane, no barriers
+        if (CLEAR) {
+            for (int p = tid; p < TS * TS; p += kThreads) {
+                const int x = X0 + (p % TS), y = Y0 + (p / TS);
+                if (x >= X1 || y >= Y1) continue;
+                const size_t pix = (size_t)y * G.W + x;
+                zb[pix] = 1e6f;
+                cb[pix * 3] = 0.0f; cb[pix * 3 + 1] = 0.0f; cb[pix * 3 + 2] = 0.0f;
+                nb[pix * 3] = 0.0f; nb[pix * 3 + 1] = 0.0f; nb[pix * 3 + 2] = 0.0f;
+                if (win) win[pix] = -1;
+            }
+        }
+        CR_STAMP(3);
+        return;   // cursor[tile] is already zero
+    }
+
     // first batch of the tile's list: index + projected vertices straight into registers
     uint32_t cur_id = 0;
     TriXYZ cur_t{};
