@@ -227,6 +227,55 @@ def test_random_triangle_soups(hip, oracle, seed, T, H, W, px, kw, mode, tile):
     compare(got, f, f"soup{seed}/{mode}/{tile}")
 
 
+@pytest.mark.parametrize("H,W,fov,zn,zf", [(480, 640, 90.0, 0.1, 1000.0), (640, 480, 60.0, 0.5, 50.0),
+                                           (1, 1, 45.0, 0.1, 1000.0), (1, 17, 45.0, 0.1, 1000.0),
+                                           (17, 1, 45.0, 0.1, 1000.0), (3, 65535, 45.0, 0.1, 1000.0),
+                                           (5000, 8, 30.0, 0.01, 10.0), (33, 47, 120.0, 0.1, 1000.0)])
+@pytest.mark.parametrize("mode", ["fused", "fused-scan", "atomic"])
+def test_frame_shapes_and_camera_parameters(hip, oracle, H, W, fov, zn, zf, mode):
+    """Non-square and degenerate frame shapes (1 pixel, single row / column, the 65535 limit),
+    non-default fov / z_near / z_far: the projection matrix and the aspect ratio enter K1."""
+    rng = np.random.default_rng(H * 7 + W)
+    tri, col, nrm = random_soup(rng, 800, max(H, W, 64), size_px=(1, 60), margin=0.5)
+    tri[..., :2] *= np.float32(2.4142137 * np.tan(np.radians(fov / 2)))   # fill this frustum
+    P = oracle.projection_matrix(fov, zn, zf, H, W)
+    f = oracle.OracleFiller(H, W, fov=fov, z_near=zn, z_far=zf)
+    assert_bit_equal(f.proj_mat, P, "oracle proj")
+    f.render_arrays(tri, col, nrm)
+    # gpu_frame builds its matrix with z_near 0.1 / z_far 1000: go through the low-level calls
+    fb = hip.FrameBuffers(H, W)
+    Pg = hip.projection_matrix(fov, zn, zf, H, W)
+    assert_bit_equal(Pg, P, "proj_mat")
+    t, c, n = _dev(tri), _dev(col), _dev(nrm)
+    if mode == "atomic":
+        hip.raster_atomic(hip.project(t, Pg, W, H), c, n, fb)
+    else:
+        plan = hip.Plan(H, W, len(tri))
+        for attempt in range(2):
+            hip.render_model(plan, t, c, n, Pg, fb, direct_bins=(mode == "fused"))
+            need, cap = plan.bin_usage()
+            if need <= cap:
+                break
+            assert attempt == 0 and plan.last_frame_direct()
+    compare(tuple(fb.numpy()) + (None,), f, f"{H}x{W} fov {fov} {mode}")
+
+
+@pytest.mark.parametrize("T", [65535, 65536, 65537])
+def test_direct_bin_triangle_limit(hip, oracle, T):
+    """Scenes of up to 65536 triangles use the direct bins, larger ones the scan path."""
+    rng = np.random.default_rng(T)
+    tri, col, nrm = random_soup(rng, T, 512, size_px=(0.5, 5))
+    f = oracle_frame(oracle, tri, col, nrm, 384, 512)
+    P = hip.projection_matrix(45.0, 0.1, 1000.0, 384, 512)
+    fb = hip.FrameBuffers(384, 512)
+    plan = hip.Plan(384, 512, T)
+    hip.render_model(plan, _dev(tri), _dev(col), _dev(nrm), P, fb)
+    assert plan.last_frame_direct() == (T <= 65536)
+    need, cap = plan.bin_usage()
+    assert need <= cap
+    compare(tuple(fb.numpy()) + (None,), f, f"T={T}")
+
+
 @pytest.mark.parametrize("mode,tile", [("fused", 16), ("fused", 32), ("fused", 64), ("fused-scan", 32),
                                        ("atomic", 0)])
 def test_adversarial_triangles(hip, oracle, mode, tile):
