@@ -46,6 +46,7 @@ SIGNATURES = {
     "crender_raster_atomic": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                      _u32, _vp, _vp]),
     "crender_selfcheck_division": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "crender_present_u8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "crender_guro_illumination": (_i32, [_vp, _vp, _f32p, _i32, _i32, _i32, _i32, _vp]),
 }
 

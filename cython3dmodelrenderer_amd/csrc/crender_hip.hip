@@ -3,20 +3,27 @@
 // Frame = K1 (projection) + K2 (rasterization) of the reference's
 // AdvancedPixelBufferFiller.render_model (.pyx:92-244), restructured for the GPU:
 //
-//   k_setup   one thread per triangle: [project,] back-face cull, pixel box, tile range;
-//             per-tile list lengths counted in an LDS histogram, flushed with one
-//             global atomic per (block, touched tile).
-//   k_scan    one workgroup: exclusive scan of the tile list lengths.
-//   k_fill    writes triangle indices into the tile lists (block-private LDS cursors,
+//   k_setup   one thread per triangle: [project,] back-face cull, pixel box, tile range, and
+//             the binning.  Scenes of up to 65536 triangles append their indices straight
+//             into fixed-capacity per-tile lists ("direct bins": the frame is two launches);
+//             larger scenes count list lengths here and go through
+//   k_scan    one workgroup: exclusive scan of the tile list lengths, and
+//   k_fill    writes triangle indices into the scanned lists (block-private LDS cursors,
 //             one global atomic per (block, touched tile) to reserve list space).
 //   k_raster  one workgroup per screen tile: a 64-bit (z, index) key per pixel lives in
-//             LDS; 16-lane groups sweep small pixel boxes and whole wavefronts sweep
-//             large ones with LDS atomic-min; then every pixel recomputes its winning
-//             fragment and stores z / colour / normal once (the clear is fused).
+//             LDS; the tile's list is swept in 4x4-pixel blocks, flattened and split evenly
+//             over sixteen 16-lane groups, with LDS atomic-min; then every pixel recomputes
+//             its winning fragment and stores z / colour / normal once (the clear is fused).
 //
-// No HBM atomics on the framebuffer and every framebuffer byte is written once per
-// frame.  Build flags (see _build.py): -ffp-contract=off, correctly rounded division,
-// denormals on — float parity with the reference depends on them.
+// No HBM atomics on the framebuffer and every framebuffer byte is written once per frame.
+// Build flags (see _build.py): -ffp-contract=off, correctly rounded division, denormals on —
+// float parity with the reference depends on them.
+//
+// CRENDER_DEBUG (environment, read once) is a bit mask of measurement knobs; none of them is
+// needed for correct results and the kernels' default paths ignore them:
+//   1 no coverage work, 2 no shading (both produce WRONG images: ablation timing only),
+//   8 XCD-banded tile map, 16 never use direct bins, 32 no sign rejection, 64 no hoisted
+//   reciprocal, 128 small-record sweep for every batch, 256 invert the scatter-dispatch rule.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -946,6 +953,24 @@ __global__ __launch_bounds__(kThreads) void k_guro(float *__restrict__ cb, const
     }
 }
 
+// ---- f3: presentation, run.py:26 — image[::-1].astype('uint8') ----------------------
+// float32 -> uint8 as numpy's C cast does it on x86-64: truncate toward zero to int32
+// (cvttss2si: NaN / out of range -> INT_MIN), keep the low byte.  Rows are flipped.
+__global__ __launch_bounds__(kThreads) void k_present_u8(const float *__restrict__ cb,
+                                                         unsigned char *__restrict__ out, int H,
+                                                         int W, int flip)
+{
+    const size_t row_elems = (size_t)W * 3, n = (size_t)H * row_elems;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const size_t y = i / row_elems, r = i - y * row_elems;
+        const float v = cb[(flip ? (size_t)(H - 1) - y : y) * row_elems + r];
+        int iv = (int)0x80000000;
+        if (v > -2147483904.0f && v < 2147483648.0f) iv = (int)v;
+        out[i] = (unsigned char)(iv & 0xFF);
+    }
+}
+
 // ---- host side --------------------------------------------------------------------
 constexpr size_t kAlign = 256;
 size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
@@ -1548,6 +1573,17 @@ int crender_raster_atomic(const float *d_tri_proj, const float *d_col, const flo
     hipLaunchKernelGGL(k_resolve_global, dim3(grid_for(npix, 8192)), dim3(kThreads), 0, s, d_tri_proj,
                        d_col, d_nrm, keys, d_z, d_color, d_normal, d_winner, W, first, npix, clear);
     CR_LAUNCH_CHECK("k_resolve_global");
+    return CRENDER_OK;
+}
+
+int crender_present_u8(const float *d_color, unsigned char *d_out, int H, int W, int flip_rows,
+                       void *stream)
+{
+    if (!d_color || !d_out || H <= 0 || W <= 0)
+        return fail(CRENDER_EINVAL, "crender_present_u8: bad argument");
+    hipLaunchKernelGGL(k_present_u8, dim3(grid_for((size_t)H * W * 3, 4096)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), d_color, d_out, H, W, flip_rows);
+    CR_LAUNCH_CHECK("k_present_u8");
     return CRENDER_OK;
 }
 

@@ -357,6 +357,18 @@ class AdvancedPixelBufferFiller:
                                                       C.byref(b), C.byref(r)), "crender_plan_timing_end")
         return n.value, b.value, r.value
 
+    def present_u8(self, flip_rows=True):
+        """uint8 [H, W, 3] device tensor of the colour plane, rows flipped — what the
+        reference's run.py:26 writes to disk (``image[::-1].astype('uint8')``)."""
+        self._check_bins()
+        self._push_host_edits()
+        out = torch.empty((self.h, self.w, 3), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.crender_present_u8(self.color_buffer.data_ptr(), out.data_ptr(),
+                                                     self.h, self.w, 1 if flip_rows else 0,
+                                                     self._stream()), "crender_present_u8")
+        return out
+
     def get_z_tensor(self):
         self._check_bins()
         return self.z_buffer

@@ -185,6 +185,11 @@ CRENDER_API int crender_selfcheck_division(const float *d_num, const float *d_de
 CRENDER_API int crender_guro_illumination(float *d_color, const float *d_normal, const float *light3,
                               int H, int W, int y0, int y1, void *stream);
 
+/* next row f3: presentation — run.py:26 `image[::-1].astype('uint8')`: float32 colour plane
+ * [H][W][3] -> uint8 [H][W][3] with numpy's C-cast semantics, rows flipped if flip_rows. */
+CRENDER_API int crender_present_u8(const float *d_color, unsigned char *d_out, int H, int W,
+                       int flip_rows, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

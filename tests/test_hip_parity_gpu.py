@@ -555,6 +555,36 @@ def test_renderer_with_illumination(oracle):
     assert_bit_equal(img_d, f.color_buffer, "Renderer.render (HIP illumination)")
 
 
+def test_present_u8_matches_numpy_cast(oracle):
+    """Row f3: image[::-1].astype('uint8') (reference: run.py:26) on the device, and the whole
+    run.py pipeline against the reference's committed render."""
+    from PIL import Image
+    from cython3dmodelrenderer_amd import Renderer
+    from cython3dmodelrenderer_amd.illumination import GuroIllumination
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    tri, col, nrm = scene("trex_inputs.npz")
+    filler = AdvancedPixelBufferFiller(1024, 1024, fov=45)
+    r = Renderer(filler, GuroIllumination([0, 0, 1]), None, 1024, 1024, on_device=True)
+    img = r.render(_M(tri, col, nrm)).cpu().numpy()
+    got = filler.present_u8().cpu().numpy()
+    assert got.dtype == np.uint8 and got.shape == (1024, 1024, 3)
+    assert (got == img[::-1].astype("uint8")).all()
+    ref_rgb = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "reference_output_T-Rex.png")).convert("RGB"))
+    assert (got[:, :, ::-1] != ref_rgb).any(axis=-1).sum() <= 200     # SURVEY section 4: ~116 racy pixels
+    # cast semantics on awkward values
+    import torch
+    vals = np.array([0.0, 0.99, 1.0, 254.999, 255.0, 255.5, 256.0, 300.7, -0.5, -1.0, -1.5, 1e9, -1e9],
+                    np.float32)
+    plane = np.resize(vals, (2, 8, 3)).astype(np.float32)
+    f2 = AdvancedPixelBufferFiller(2, 8, fov=45)
+    f2.color_buffer.copy_(torch.from_numpy(plane))
+    with np.errstate(invalid="ignore"):
+        want = plane[::-1].astype("uint8")
+    got2 = f2.present_u8().cpu().numpy()
+    inrange = (plane[::-1] > -2**31) & (plane[::-1] < 2**31)
+    assert (got2[inrange] == want[inrange]).all()
+
+
 # ---- full BASELINE.json sizes ----------------------------------------------------------
 @pytest.mark.parametrize("name,fixture,res", [("bunny4096", "bunny_inputs.npz", 4096),
                                               ("trex8192", "trex_inputs.npz", 8192)])
