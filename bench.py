@@ -116,12 +116,13 @@ def main():
     filler = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile,
                                        row_strip=(y0, y1) if world > 1 else None,
                                        pipeline=not args.no_pipeline)
-    planes = [filler.z_buffer, filler.color_buffer, filler.normals_buffer]
 
     def step(pipelined=True):
         filler.render_frame(pipelined=pipelined)
         if world > 1 and not args.no_gather:
-            D.all_gather_strips(planes, H, rank, world)
+            filler.join()            # the collective runs on this stream, the frame on the pipeline's
+            D.all_gather_strips([filler.z_buffer, filler.color_buffer, filler.normals_buffer],
+                                H, rank, world)
 
     # upload the model once and make sure the bin lists are large enough (untimed)
     filler.render_arrays(tri, col, nrm, clear=True)
@@ -186,7 +187,9 @@ def main():
             "config": {"workload": args.workload, "triangles": T, "height": H, "width": W,
                        "fov": fov, "row_strips": world, "tile": filler.tile or "auto",
                        "frame": "clear + project + rasterize, model resident in HBM",
-                       "pipelined": bool(not args.no_pipeline),
+                       "pipelined": (False if args.no_pipeline else
+                                     "swap chain of two: consecutive frames render into alternating "
+                                     "framebuffer sets on two streams (each frame complete)"),
                        "all_gather": bool(world > 1 and not args.no_gather)},
             "mtris_per_sec": T * fps / 1e6,
             "frame_algorithmic_bytes": algorithmic_bytes(T, H, W),

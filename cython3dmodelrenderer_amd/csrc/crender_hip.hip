@@ -1059,18 +1059,21 @@ struct crender_plan {
     uint32_t *entries() const { return reinterpret_cast<uint32_t *>(ws + L.off_entries); }
 };
 
-// Double-buffered frames: bin pass of frame i+1 on an auxiliary stream overlapping the raster
-// pass of frame i on the caller's stream (crender_pipeline_*).
+// Swap chain of two (crender_pipeline_*): frame i runs entirely on the pipeline's stream i & 1
+// with plan i & 1 into the framebuffer set the caller passes for it; consecutive frames target
+// DIFFERENT framebuffer sets, so nothing orders them and they overlap freely on the GPU.  No HIP
+// event sits between frames: on MI355X / ROCm 7.2 an event record + cross-stream wait opens a
+// 7-12 us bubble (rocprofv3 timeline, profiles/r01), a third of a 1024^2 frame.
 struct crender_pipeline {
     crender_plan *plan[2];
-    hipStream_t aux = nullptr;
-    hipEvent_t prep_done[2] = {nullptr, nullptr};
-    hipEvent_t draw_done[2] = {nullptr, nullptr};
+    hipStream_t s[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
     hipEvent_t mark = nullptr;
-    bool drawn[2] = {false, false};
-    uint64_t n = 0;
+    uint64_t n = 0;           // frames submitted since the last join
     const void *last_tri = nullptr, *last_nrm = nullptr;
     int64_t last_T = -1;
+    hipStream_t last_caller = nullptr;
+    bool synced = false;
 };
 
 namespace {
@@ -1468,6 +1471,15 @@ int crender_selfcheck_division(const float *d_num, const float *d_den, float *d_
     return CRENDER_OK;
 }
 
+static int crender_render_model_on(crender_plan *plan, const float *d_tri, const float *d_col,
+                                   const float *d_nrm, int64_t T, const float *P16, float *d_z,
+                                   float *d_color, float *d_normal, int32_t *d_winner, unsigned flags,
+                                   hipStream_t s)
+{
+    return tile_frame(plan, P16 != nullptr, d_tri, d_col, d_nrm, T, P16, d_z, d_color, d_normal,
+                      d_winner, flags, s);
+}
+
 int crender_pipeline_create(crender_pipeline **out, crender_plan *plan_a, crender_plan *plan_b)
 {
     if (!out || !plan_a || !plan_b || plan_a == plan_b)
@@ -1477,10 +1489,10 @@ int crender_pipeline_create(crender_pipeline **out, crender_plan *plan_a, crende
     if (!p) return fail(CRENDER_ENOMEM, "crender_pipeline_create: host allocation failed");
     p->plan[0] = plan_a;
     p->plan[1] = plan_b;
-    hipError_t e = hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking);
+    hipError_t e = hipSuccess;
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-        e = hipEventCreateWithFlags(&p->prep_done[k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->draw_done[k], hipEventDisableTiming);
+        e = hipStreamCreateWithFlags(&p->s[k], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done[k], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->mark, hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -1494,13 +1506,12 @@ int crender_pipeline_create(crender_pipeline **out, crender_plan *plan_a, crende
 void crender_pipeline_destroy(crender_pipeline *p)
 {
     if (!p) return;
-    if (p->aux) (void)hipStreamSynchronize(p->aux);
     for (int k = 0; k < 2; ++k) {
-        if (p->prep_done[k]) (void)hipEventDestroy(p->prep_done[k]);
-        if (p->draw_done[k]) (void)hipEventDestroy(p->draw_done[k]);
+        if (p->s[k]) (void)hipStreamSynchronize(p->s[k]);
+        if (p->done[k]) (void)hipEventDestroy(p->done[k]);
+        if (p->s[k]) (void)hipStreamDestroy(p->s[k]);
     }
     if (p->mark) (void)hipEventDestroy(p->mark);
-    if (p->aux) (void)hipStreamDestroy(p->aux);
     delete p;
 }
 
@@ -1509,37 +1520,37 @@ int crender_pipeline_frame(crender_pipeline *p, const float *d_tri, const float 
                            float *d_normal, int32_t *d_winner, unsigned flags, void *stream)
 {
     if (!p) return fail(CRENDER_EINVAL, "null pipeline");
-    hipStream_t main_s = static_cast<hipStream_t>(stream);
-    if (d_tri != p->last_tri || d_nrm != p->last_nrm || T != p->last_T) {
-        // new inputs: whatever produced them was enqueued on the caller's stream
-        CR_HIP(hipEventRecord(p->mark, main_s));
-        CR_HIP(hipStreamWaitEvent(p->aux, p->mark, 0));
-        p->last_tri = d_tri; p->last_nrm = d_nrm; p->last_T = T;
+    hipStream_t caller = static_cast<hipStream_t>(stream);
+    if (!p->synced || d_tri != p->last_tri || d_nrm != p->last_nrm || T != p->last_T ||
+        caller != p->last_caller) {
+        // new inputs, or the first frame after a join: whatever produced the inputs, and whatever
+        // touched the framebuffers last, was enqueued on the caller's stream
+        CR_HIP(hipEventRecord(p->mark, caller));
+        CR_HIP(hipStreamWaitEvent(p->s[0], p->mark, 0));
+        CR_HIP(hipStreamWaitEvent(p->s[1], p->mark, 0));
+        p->last_tri = d_tri; p->last_nrm = d_nrm; p->last_T = T; p->last_caller = caller;
+        p->synced = true;
     }
     const int k = (int)(p->n & 1);
+    // plan k and framebuffer set k were last used by frame n - 2, earlier on this same stream
+    int rc = crender_render_model_on(p->plan[k], d_tri, d_col, d_nrm, T, P16, d_z, d_color, d_normal,
+                                     d_winner, flags, p->s[k]);
+    if (rc != CRENDER_OK) return rc;
     p->n++;
-    if (p->drawn[k]) CR_HIP(hipStreamWaitEvent(p->aux, p->draw_done[k], 0));  // plan k's bins are free
-    int rc = crender_prepare(p->plan[k], d_tri, d_nrm, T, P16, flags, p->aux);
-    if (rc != CRENDER_OK) return rc;
-    CR_HIP(hipEventRecord(p->prep_done[k], p->aux));
-    CR_HIP(hipStreamWaitEvent(main_s, p->prep_done[k], 0));
-    rc = crender_draw(p->plan[k], P16 ? nullptr : d_tri, d_col, d_nrm, T, d_z, d_color, d_normal,
-                      d_winner, flags, stream);
-    if (rc != CRENDER_OK) return rc;
-    CR_HIP(hipEventRecord(p->draw_done[k], main_s));
-    p->drawn[k] = true;
     return CRENDER_OK;
 }
 
 int crender_pipeline_join(crender_pipeline *p, void *stream)
 {
     if (!p) return fail(CRENDER_EINVAL, "null pipeline");
-    // the aux stream only ever runs bin passes whose raster passes are already ordered on the
-    // caller's stream, so waiting for the last prepare is enough
-    CR_HIP(hipEventRecord(p->mark, p->aux));
-    CR_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->mark, 0));
-    p->last_tri = p->last_nrm = nullptr;   // next frame re-synchronises the aux stream
-    p->last_T = -1;
+    hipStream_t caller = static_cast<hipStream_t>(stream);
+    const int used = p->n >= 2 ? 2 : (int)p->n;      // frame 0 ran on stream 0, frame 1 on stream 1
+    for (int k = 0; k < used; ++k) {
+        CR_HIP(hipEventRecord(p->done[k], p->s[k]));
+        CR_HIP(hipStreamWaitEvent(caller, p->done[k], 0));
+    }
+    p->n = 0;
+    p->synced = false;   // the next frame re-synchronises with the caller's stream
     return CRENDER_OK;
 }
 

@@ -55,10 +55,12 @@ def _as_device_f32(a, name, device):
 
 
 class _FramePipeline:
-    """Double-buffered frames for ``render_frame``: the bin pass of frame i+1 overlaps the
-    raster pass of frame i (``crender_pipeline_*``: two plans, a second stream and the events
-    between them live in the library, so a frame is ONE call from Python).  Every frame still
-    does all of its work; only consecutive frames overlap."""
+    """Swap chain of two for ``render_frame`` (``crender_pipeline_*``): frame i renders on the
+    library's stream i & 1 with plan i & 1 into framebuffer set i & 1, so consecutive frames
+    overlap on the GPU with no event between them.  Every frame still does all of its work
+    (clear + project + bin + rasterize) into a complete framebuffer; the filler's
+    ``z_buffer / color_buffer / normals_buffer`` always name the most recently submitted frame's
+    set.  ``join`` orders the caller's stream after all submitted frames."""
 
     def __init__(self, filler, T):
         self.lib = filler._lib
@@ -79,7 +81,13 @@ class _FramePipeline:
         self.handle = C.c_void_p()
         _capi.check(self.lib.crender_pipeline_create(C.byref(self.handle), self.plans[0], self.plans[1]),
                     "crender_pipeline_create")
+        # front / back framebuffer sets: the filler's own buffers and a second copy of them
+        front = (filler.z_buffer, filler.color_buffer, filler.normals_buffer, filler.winner_buffer)
+        back = tuple(None if t is None else t.clone() for t in front)
+        self.sets = [front, back]
+        self.k = 0                 # set / stream / plan of the next frame (the library counts alike)
         self.n = 0
+        self.pending = False
         self._args = None
 
     def close(self):
@@ -93,20 +101,29 @@ class _FramePipeline:
     def frame(self, filler):
         if self._args is None or self._args[0] is not filler._inputs:
             tri, col, nrm = filler._inputs
-            # everything but the stream is fixed while the resident model is: build the
-            # ctypes argument tuple once
-            self._args = (filler._inputs,
-                          (self.handle, tri.data_ptr(), col.data_ptr(), nrm.data_ptr(), tri.shape[0],
-                           filler._P, filler.z_buffer.data_ptr(), filler.color_buffer.data_ptr(),
-                           filler.normals_buffer.data_ptr(), filler._win_ptr(),
-                           _capi.FUSED_CLEAR | filler._extra_flags))
-        rc = self.lib.crender_pipeline_frame(*self._args[1], torch.cuda.current_stream(self.device).cuda_stream)
+            # everything but the stream is fixed while the resident model is: build the ctypes
+            # argument tuples (one per framebuffer set) once
+            per_set = []
+            for z, c, n, w in self.sets:
+                per_set.append((self.handle, tri.data_ptr(), col.data_ptr(), nrm.data_ptr(), tri.shape[0],
+                                filler._P, z.data_ptr(), c.data_ptr(), n.data_ptr(),
+                                None if w is None else w.data_ptr(),
+                                _capi.FUSED_CLEAR | filler._extra_flags))
+            self._args = (filler._inputs, per_set)
+        rc = self.lib.crender_pipeline_frame(*self._args[1][self.k],
+                                             torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _capi.check(rc, "crender_pipeline_frame")
+        # the filler's buffers are now this frame's
+        filler.z_buffer, filler.color_buffer, filler.normals_buffer, filler.winner_buffer = self.sets[self.k]
+        self.k ^= 1
         self.n += 1
+        self.pending = True
 
     def join(self, filler):
         _capi.check(self.lib.crender_pipeline_join(self.handle, filler._stream()), "crender_pipeline_join")
+        self.pending = False
+        self.k = 0                 # the library restarts its frame parity at a join
 
     def overflowed(self, filler):
         """Synchronising check of both plans' bin lists."""
@@ -205,8 +222,15 @@ class AdvancedPixelBufferFiller:
                                                           C.byref(cap)), "crender_plan_last_bin_usage")
         self._plan_capacity = cap.value
 
+    def _join_pipe(self):
+        """Pipelined frames run on the pipeline's streams: make the current stream wait for them
+        before anything else reads or writes the buffers."""
+        if self._pipe is not None and self._pipe.pending:
+            self._pipe.join(self)
+
     def _push_host_edits(self):
         """Carry in-place edits of handed-out numpy views back to the device."""
+        self._join_pipe()
         if not self._host_exposed:
             return
         for name, buf in (("z", self.z_buffer), ("color", self.color_buffer),
@@ -219,6 +243,7 @@ class AdvancedPixelBufferFiller:
         return self.winner_buffer.data_ptr() if self.winner_buffer is not None else None
 
     def _launch(self, flags):
+        self._join_pipe()
         tri, col, nrm = self._inputs
         T = tri.shape[0]
         self._ensure_plan(T)
@@ -305,16 +330,13 @@ class AdvancedPixelBufferFiller:
     def render_frame(self, pipelined=None):
         """One benchmark frame: clear + project + rasterize the resident model
         (SURVEY.md section 8d 'one frame').  Inputs must have been set by a previous
-        render_model / render_arrays call.  With ``pipeline=True`` (constructor) consecutive
-        frames overlap: the next frame's projection + binning runs on a second stream while
-        this frame rasterizes."""
+        render_model / render_arrays call.  With ``pipeline=True`` (constructor) the filler is
+        a swap chain of two: consecutive frames render into alternating framebuffer sets on two
+        streams and overlap on the GPU; the buffer attributes and getters always refer to the
+        most recently submitted frame."""
         use_pipe = self._pipeline if pipelined is None else (pipelined and self._pipeline)
         if not use_pipe:
-            if self._pipe is not None and self._pipe.n > 0:
-                # plain frames after pipelined ones: let the pipeline's own stream drain first
-                self._pipe.join(self)
-                self._pipe.n = 0
-            self._launch(_capi.FUSED_CLEAR)
+            self._launch(_capi.FUSED_CLEAR)      # (joins the pipeline first if frames are pending)
             return
         T = self._inputs[0].shape[0]
         if self._pipe is None or T > self._pipe.max_T:
@@ -327,6 +349,7 @@ class AdvancedPixelBufferFiller:
 
     def clear(self):
         """Back to the state __cinit__ leaves (.pyx:65-67)."""
+        self._join_pipe()
         with torch.cuda.device(self.device):
             _capi.check(self._lib.crender_clear(self.z_buffer.data_ptr(), self.color_buffer.data_ptr(),
                                                 self.normals_buffer.data_ptr(), self._win_ptr(),
@@ -334,6 +357,11 @@ class AdvancedPixelBufferFiller:
                         "crender_clear")
         self._host_fresh = False
         self._host_exposed = False
+
+    def join(self):
+        """Order the current stream after any pipelined frames still in flight (no host sync).
+        Needed before other stream work touches the buffers, e.g. an all-gather of strips."""
+        self._join_pipe()
 
     def synchronize(self):
         self._check_bins()

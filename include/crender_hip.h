@@ -144,13 +144,20 @@ CRENDER_API int crender_draw(crender_plan *plan, const float *d_tri_proj, const 
                  const float *d_nrm, int64_t T, float *d_z, float *d_color, float *d_normal,
                  int32_t *d_winner, unsigned flags, void *stream);
 
-/* The double buffering above, ready-made: one call per frame.  Frame i's crender_draw runs
- * on `stream`; frame i+1's crender_prepare runs on a stream the pipeline owns, into the other
- * plan, ordered by events.  Results are those of crender_render_model with the same
- * arguments.  If the input pointers or T change, the pipeline first lets its stream catch
- * up with `stream`; if inputs are overwritten IN PLACE, call crender_pipeline_join first.
- * crender_pipeline_join makes `stream` wait for the pipeline's own stream (before using
- * the plans directly or destroying them).  Bin-list overflow is queried per plan as usual. */
+/* A swap chain of two, ready-made: one call per frame, consecutive frames overlap on the GPU.
+ * The pipeline owns two streams; frame i runs (bin pass + raster pass) on stream i & 1 with
+ * plan i & 1.  CONSECUTIVE FRAMES MUST TARGET DIFFERENT FRAMEBUFFER SETS (front / back): nothing
+ * orders frame i against frame i + 1.  Frames i and i + 2 share a stream and may share buffers.
+ * Each frame's result equals crender_render_model's with the same arguments.
+ *   - `stream` is the CALLER's stream: at the first frame after creation or a join, and when the
+ *     input pointers, T or the stream change, the pipeline's streams first wait for everything
+ *     enqueued on it (uploads, earlier use of the framebuffers).  If inputs are overwritten IN
+ *     PLACE, call crender_pipeline_join first.
+ *   - crender_pipeline_join makes `stream` wait for all submitted frames.  Call it before a
+ *     framebuffer is read or written by anything else, before using the plans directly and
+ *     before destroying them.  Bin-list overflow is queried per plan as usual, after a join.
+ * No HIP event separates frames: an event record + cross-stream wait costs a 7-12 us bubble on
+ * MI355X, which is why the raster passes are decoupled by buffers instead of chained. */
 typedef struct crender_pipeline crender_pipeline;
 CRENDER_API int crender_pipeline_create(crender_pipeline **out, crender_plan *plan_a, crender_plan *plan_b);
 CRENDER_API void crender_pipeline_destroy(crender_pipeline *pipeline);

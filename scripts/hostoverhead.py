@@ -1,6 +1,6 @@
 """Host issue time vs GPU time per frame (T-Rex 1024^2), plain and pipelined."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cython3dmodelrenderer_amd import scenes
 from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
