@@ -153,6 +153,11 @@ def main():
     # scripts/hostoverhead.py vs this loop); the events loop's own frame time is reported too.
     step(pipelined=False)            # also makes sure the single-stream plan exists
     barrier()
+    t2 = time.perf_counter()         # the same K frames one at a time on one stream: frame latency
+    for _ in range(args.steps):
+        step(pipelined=False)
+    barrier()
+    elapsed_single = time.perf_counter() - t2
     filler.timing_begin(args.steps)
     barrier()
     t1 = time.perf_counter()
@@ -188,8 +193,8 @@ def main():
                        "fov": fov, "row_strips": world, "tile": filler.tile or "auto",
                        "frame": "clear + project + rasterize, model resident in HBM",
                        "pipelined": (False if args.no_pipeline else
-                                     "swap chain of two: consecutive frames render into alternating "
-                                     "framebuffer sets on two streams (each frame complete)"),
+                                     "swap chain of 3 (triple buffering): frames in flight render into "
+                                     "separate framebuffer sets on separate streams, each frame complete"),
                        "all_gather": bool(world > 1 and not args.no_gather)},
             "mtris_per_sec": T * fps / 1e6,
             "frame_algorithmic_bytes": algorithmic_bytes(T, H, W),
@@ -197,6 +202,7 @@ def main():
             "kernel_ms": {"binning_passes": bin_ms, "raster": raster_ms, "timed_frames": n_timed,
                           "how": "HIP events on the frame's stream, second pass of K steps",
                           "ms_per_step_with_events": elapsed_events / args.steps * 1e3},
+            "ms_per_frame_single_stream": elapsed_single / args.steps * 1e3,
             "roofline": {"kernel": "k_raster", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": abytes,

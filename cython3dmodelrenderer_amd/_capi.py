@@ -38,7 +38,7 @@ SIGNATURES = {
     "crender_render_model": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32p, _vp, _vp, _vp, _vp, _u32, _vp]),
     "crender_prepare": (_i32, [_vp, _vp, _vp, _i64, _f32p, _u32, _vp]),
     "crender_draw": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _u32, _vp]),
-    "crender_pipeline_create": (_i32, [C.POINTER(_vp), _vp, _vp]),
+    "crender_pipeline_create": (_i32, [C.POINTER(_vp), C.POINTER(_vp), _i32]),
     "crender_pipeline_destroy": (None, [_vp]),
     "crender_pipeline_frame": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32p, _vp, _vp, _vp, _vp, _u32, _vp]),
     "crender_pipeline_join": (_i32, [_vp, _vp]),

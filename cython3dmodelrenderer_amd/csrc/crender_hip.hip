@@ -1059,15 +1059,17 @@ struct crender_plan {
     uint32_t *entries() const { return reinterpret_cast<uint32_t *>(ws + L.off_entries); }
 };
 
-// Swap chain of two (crender_pipeline_*): frame i runs entirely on the pipeline's stream i & 1
-// with plan i & 1 into the framebuffer set the caller passes for it; consecutive frames target
-// DIFFERENT framebuffer sets, so nothing orders them and they overlap freely on the GPU.  No HIP
+// Swap chain of `depth` (crender_pipeline_*): frame i runs entirely on the pipeline's stream
+// i % depth with plan i % depth into the framebuffer set the caller passes for it; frames in
+// flight target DIFFERENT framebuffer sets, so nothing orders them and they overlap freely on the GPU.  No HIP
 // event sits between frames: on MI355X / ROCm 7.2 an event record + cross-stream wait opens a
 // 7-12 us bubble (rocprofv3 timeline, profiles/r01), a third of a 1024^2 frame.
+constexpr int kMaxPipelineDepth = 8;
 struct crender_pipeline {
-    crender_plan *plan[2];
-    hipStream_t s[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
+    int depth = 0;
+    crender_plan *plan[kMaxPipelineDepth] = {};
+    hipStream_t s[kMaxPipelineDepth] = {};
+    hipEvent_t done[kMaxPipelineDepth] = {};
     hipEvent_t mark = nullptr;
     uint64_t n = 0;           // frames submitted since the last join
     const void *last_tri = nullptr, *last_nrm = nullptr;
@@ -1480,17 +1482,21 @@ static int crender_render_model_on(crender_plan *plan, const float *d_tri, const
                       d_winner, flags, s);
 }
 
-int crender_pipeline_create(crender_pipeline **out, crender_plan *plan_a, crender_plan *plan_b)
+int crender_pipeline_create(crender_pipeline **out, crender_plan *const *plans, int depth)
 {
-    if (!out || !plan_a || !plan_b || plan_a == plan_b)
-        return fail(CRENDER_EINVAL, "crender_pipeline_create: need two distinct plans");
+    if (!out || !plans || depth < 2 || depth > kMaxPipelineDepth)
+        return fail(CRENDER_EINVAL, "crender_pipeline_create: need 2..8 plans");
+    for (int i = 0; i < depth; ++i)
+        for (int j = 0; j <= i; ++j)
+            if (!plans[i] || (j < i && plans[i] == plans[j]))
+                return fail(CRENDER_EINVAL, "crender_pipeline_create: plans must be distinct");
     *out = nullptr;
     crender_pipeline *p = new (std::nothrow) crender_pipeline();
     if (!p) return fail(CRENDER_ENOMEM, "crender_pipeline_create: host allocation failed");
-    p->plan[0] = plan_a;
-    p->plan[1] = plan_b;
+    p->depth = depth;
     hipError_t e = hipSuccess;
-    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    for (int k = 0; k < depth && e == hipSuccess; ++k) {
+        p->plan[k] = plans[k];
         e = hipStreamCreateWithFlags(&p->s[k], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done[k], hipEventDisableTiming);
     }
@@ -1506,7 +1512,7 @@ int crender_pipeline_create(crender_pipeline **out, crender_plan *plan_a, crende
 void crender_pipeline_destroy(crender_pipeline *p)
 {
     if (!p) return;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < p->depth; ++k) {
         if (p->s[k]) (void)hipStreamSynchronize(p->s[k]);
         if (p->done[k]) (void)hipEventDestroy(p->done[k]);
         if (p->s[k]) (void)hipStreamDestroy(p->s[k]);
@@ -1526,13 +1532,12 @@ int crender_pipeline_frame(crender_pipeline *p, const float *d_tri, const float 
         // new inputs, or the first frame after a join: whatever produced the inputs, and whatever
         // touched the framebuffers last, was enqueued on the caller's stream
         CR_HIP(hipEventRecord(p->mark, caller));
-        CR_HIP(hipStreamWaitEvent(p->s[0], p->mark, 0));
-        CR_HIP(hipStreamWaitEvent(p->s[1], p->mark, 0));
+        for (int k = 0; k < p->depth; ++k) CR_HIP(hipStreamWaitEvent(p->s[k], p->mark, 0));
         p->last_tri = d_tri; p->last_nrm = d_nrm; p->last_T = T; p->last_caller = caller;
         p->synced = true;
     }
-    const int k = (int)(p->n & 1);
-    // plan k and framebuffer set k were last used by frame n - 2, earlier on this same stream
+    const int k = (int)(p->n % (uint64_t)p->depth);
+    // plan k and framebuffer set k were last used by frame n - depth, earlier on this same stream
     int rc = crender_render_model_on(p->plan[k], d_tri, d_col, d_nrm, T, P16, d_z, d_color, d_normal,
                                      d_winner, flags, p->s[k]);
     if (rc != CRENDER_OK) return rc;
@@ -1544,7 +1549,7 @@ int crender_pipeline_join(crender_pipeline *p, void *stream)
 {
     if (!p) return fail(CRENDER_EINVAL, "null pipeline");
     hipStream_t caller = static_cast<hipStream_t>(stream);
-    const int used = p->n >= 2 ? 2 : (int)p->n;      // frame 0 ran on stream 0, frame 1 on stream 1
+    const int used = p->n >= (uint64_t)p->depth ? p->depth : (int)p->n;   // frame j ran on stream j
     for (int k = 0; k < used; ++k) {
         CR_HIP(hipEventRecord(p->done[k], p->s[k]));
         CR_HIP(hipStreamWaitEvent(caller, p->done[k], 0));

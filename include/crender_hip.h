@@ -144,22 +144,24 @@ CRENDER_API int crender_draw(crender_plan *plan, const float *d_tri_proj, const 
                  const float *d_nrm, int64_t T, float *d_z, float *d_color, float *d_normal,
                  int32_t *d_winner, unsigned flags, void *stream);
 
-/* A swap chain of two, ready-made: one call per frame, consecutive frames overlap on the GPU.
- * The pipeline owns two streams; frame i runs (bin pass + raster pass) on stream i & 1 with
- * plan i & 1.  CONSECUTIVE FRAMES MUST TARGET DIFFERENT FRAMEBUFFER SETS (front / back): nothing
- * orders frame i against frame i + 1.  Frames i and i + 2 share a stream and may share buffers.
- * Each frame's result equals crender_render_model's with the same arguments.
+/* A swap chain, ready-made: one call per frame, up to `depth` (2..8) frames overlap on the GPU.
+ * The pipeline owns `depth` streams; frame i runs (bin pass + raster pass) on stream i % depth
+ * with plans[i % depth].  FRAMES IN FLIGHT MUST TARGET DIFFERENT FRAMEBUFFER SETS (a swap
+ * chain): nothing orders frame i against frames i+1 .. i+depth-1.  Frames i and i + depth share
+ * a stream and may share buffers.  Each frame's result equals crender_render_model's with the
+ * same arguments.
  *   - `stream` is the CALLER's stream: at the first frame after creation or a join, and when the
  *     input pointers, T or the stream change, the pipeline's streams first wait for everything
  *     enqueued on it (uploads, earlier use of the framebuffers).  If inputs are overwritten IN
  *     PLACE, call crender_pipeline_join first.
- *   - crender_pipeline_join makes `stream` wait for all submitted frames.  Call it before a
- *     framebuffer is read or written by anything else, before using the plans directly and
- *     before destroying them.  Bin-list overflow is queried per plan as usual, after a join.
+ *   - crender_pipeline_join makes `stream` wait for all submitted frames and restarts the frame
+ *     counter at 0.  Call it before a framebuffer is read or written by anything else, before
+ *     using the plans directly and before destroying them.  Bin-list overflow is queried per
+ *     plan as usual, after a join.
  * No HIP event separates frames: an event record + cross-stream wait costs a 7-12 us bubble on
- * MI355X, which is why the raster passes are decoupled by buffers instead of chained. */
+ * MI355X, which is why frames are decoupled by buffers instead of chained. */
 typedef struct crender_pipeline crender_pipeline;
-CRENDER_API int crender_pipeline_create(crender_pipeline **out, crender_plan *plan_a, crender_plan *plan_b);
+CRENDER_API int crender_pipeline_create(crender_pipeline **out, crender_plan *const *plans, int depth);
 CRENDER_API void crender_pipeline_destroy(crender_pipeline *pipeline);
 CRENDER_API int crender_pipeline_frame(crender_pipeline *pipeline, const float *d_tri, const float *d_col,
                            const float *d_nrm, int64_t T, const float *P16,

@@ -512,17 +512,19 @@ def test_filler_recovers_from_direct_bin_overflow(oracle):
     assert need2 <= cap2 and cap2 != 1024       # general path now
 
 
-def test_pipelined_frames_are_exact(oracle):
-    """render_frame in pipeline mode overlaps the next frame's bin pass with this frame's raster
-    pass (two plans, two streams).  Whatever the interleaving, the buffers after frame N are
-    frame N's: checked after bursts of frames and after switching the resident model mid-stream."""
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_pipelined_frames_are_exact(oracle, depth):
+    """render_frame in pipeline mode is a swap chain: up to `depth` frames in flight on as many
+    streams, plans and framebuffer sets.  Whatever the interleaving, the filler's buffers after
+    frame N are frame N's: checked after bursts of frames and after switching the resident model
+    mid-stream."""
     from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
     trex = scene("trex_inputs.npz")
     cube = scene("cube_inputs.npz")
     rng = np.random.default_rng(4)
     soup = random_soup(rng, 20000, 300, size_px=(1, 30))
     H, W = 300, 420
-    filler = AdvancedPixelBufferFiller(H, W, fov=45, pipeline=True, track_winner=True)
+    filler = AdvancedPixelBufferFiller(H, W, fov=45, pipeline=True, pipeline_depth=depth, track_winner=True)
     for model, bursts in ((trex, (1, 2, 7)), (soup, (3, 1)), (cube, (2,)), (trex, (5,))):
         f = oracle.OracleFiller(H, W, fov=45)
         f.render_arrays(*model)
