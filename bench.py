@@ -46,27 +46,50 @@ def load_traffic(workload):
         return None
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(tri, col, nrm, H, W, fov, budget_s=12.0):
-    """Version-C-shaped CPU oracle on this host's cores, same frame definition."""
+    """Version-C-shaped CPU oracle on this host's cores, same frame definition.  The headline
+    figure is 16 threads (the README's best column); 1 and 8 threads (its other columns) are
+    sampled too.  Bounded: about `budget_s` seconds per thread count at most."""
     from oracle import oracle as O
     ncpu = os.cpu_count() or 1
-    threads = min(16, ncpu)                      # the README's best column is 16 threads
-    f = O.OracleFiller(H, W, fov=fov, n_threads=threads, mode="omp")
 
-    def frame():
-        f.clear()
-        f.render_arrays(tri, col, nrm)
+    def measure(threads, budget):
+        f = O.OracleFiller(H, W, fov=fov, n_threads=threads, mode="omp")
 
-    t0 = time.perf_counter()
-    frame()                                      # warm-up, also sizes the sample
-    one = time.perf_counter() - t0
-    n = int(max(1, min(200, budget_s / max(one, 1e-4))))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        frame()
-    dt = (time.perf_counter() - t0) / n
+        def frame():
+            f.clear()
+            f.render_arrays(tri, col, nrm)
+
+        t0 = time.perf_counter()
+        frame()                                  # warm-up, also sizes the sample
+        one = time.perf_counter() - t0
+        n = int(max(1, min(200, budget / max(one, 1e-4))))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            frame()
+        return (time.perf_counter() - t0) / n, n
+
+    threads = min(16, ncpu)
+    dt, n = measure(threads, budget_s)
+    by_threads = {str(threads): 1.0 / dt}
+    for t in (1, 8):
+        if t < ncpu and t != threads:
+            d, _ = measure(t, budget_s / 4)
+            by_threads[str(t)] = 1.0 / d
     return {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "ms_per_frame": dt * 1e3, "host_cpus": ncpu,
+            "ms_per_frame": dt * 1e3, "host_cpus": ncpu, "cpu_model": cpu_model(),
+            "frames_per_s_by_threads": by_threads,
             "sample": f"{n} full frames of the same workload (clear + project + raster), "
                       f"OpenMP dynamic schedule + per-pixel locks, {threads} threads"}
 
