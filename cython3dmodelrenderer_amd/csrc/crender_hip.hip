@@ -533,6 +533,7 @@ struct WorkQueue {
     uint32_t box_wh[kThreads];    // bw  | bh  << 16  (0 = no work)
     uint32_t blk_scan[kThreads];  // exclusive prefix of block counts within the wavefront
     uint32_t wave_blocks[kThreads / 64];
+    unsigned long long mask[kThreads];  // large-record batches: blocks that survive the cull
 };
 
 // The record a 16-lane group is sweeping.  T = TriXYZ (small records: the edge constants are
@@ -586,6 +587,36 @@ CR_DEV int find_record(const WorkQueue &q, const uint32_t *wo, int p, uint32_t &
     }
     first_block = pl - q.blk_scan[lo];
     return lo;
+}
+
+// Coarse pass of a large-record batch: one lane per dense 4x4 block; surviving blocks are
+// recorded in q.mask.
+CR_DEV void coarse_cull(WorkQueue &q, const uint32_t *wo, int total, int tid,
+                                                      bool keep_all)
+{
+    for (int p = tid; p < total; p += kThreads) {
+        uint32_t first;
+        const int r = find_record(q, wo, p, first);
+        const TriSetup s = make_setup(TriXYZ{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
+                                             q.x2[r], q.y2[r], q.z2[r]}, false);
+        const uint32_t xy = q.box_xy[r], wh = q.box_wh[r];
+        const int nbx = (int)((wh & 0xFFFF) + 3) >> 2;
+        const int b = (int)first;
+        const int by = (int)(((float)b + 0.5f) * (1.0f / (float)nbx)), bx = b - by * nbx;
+        const int xa = (int)(xy & 0xFFFF) + (bx << 2), ya = (int)(xy >> 16) + (by << 2);
+        // t_k = num_k * rej_k (>= -2^-60 unless surely outside) grows with Y when l_k1 * rej_k > 0
+        // and with X when l_k2 * rej_k < 0: evaluate each edge at the corner where it is largest
+        const float fxa = (float)xa, fxb = (float)(xa + 3), fya = (float)ya, fyb = (float)(ya + 3);
+        auto worst = [&](float l1, float l2, float ya_, float xb_, float rej) {
+            const float fy = (l1 * rej >= 0.0f) ? fyb : fya;
+            const float fx = (l2 * rej >= 0.0f) ? fxa : fxb;
+            return (l1 * (fy - ya_) - l2 * (fx - xb_)) * rej;
+        };
+        const bool o1 = worst(s.l01, s.l02, s.y2, s.x2, s.rej1) < -kRejTiny;
+        const bool o2 = worst(s.l11, s.l12, s.y0, s.x0, s.rej2) < -kRejTiny;
+        const bool o3 = worst(s.l21, s.l22, s.y1, s.x1, s.rej3) < -kRejTiny;
+        if (keep_all || !(o1 || o2 || o3)) atomicOr(&q.mask[r], 1ull << b);
+    }
 }
 
 #ifdef CRENDER_STAMPS
@@ -771,42 +802,102 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ p
                     }
                 }
             } else {
-                // Large records (>= 16 blocks on average): each wavefront takes a contiguous
-                // quarter and its four groups every fourth block of it, so the four blocks a
-                // wavefront works on at a time are neighbours: their "surely outside" outcomes
-                // correlate and the divisions are skipped wave-wide (raster_math.h (1)); the
-                // divisions that remain use the hoisted reciprocal (raster_math.h (2)).
-                const int wchunk = (total + kThreads / 64 - 1) / (kThreads / 64);
-                int p = wave * wchunk + ((tid >> 4) & 3);
-                const int pend = ((wave + 1) * wchunk < total) ? ((wave + 1) * wchunk) : total;
+                // Large records (>= 16 blocks on average).  A triangle fills at most half of its
+                // pixel box, so first a coarse pass (one LANE per 4x4 block) discards blocks that
+                // lie entirely outside one edge; the survivors are then swept (one 16-lane GROUP
+                // per block): each wavefront takes a contiguous quarter of them and its four
+                // groups consecutive survivors, so the four blocks a wavefront works on at a
+                // time are neighbours.  In the sweep, lanes whose sign test is certainly negative
+                // are dead before any division (skipped wave-wide when nobody is live,
+                // raster_math.h (1)); the divisions that remain use the hoisted reciprocal (2).
                 const bool allow_rej = !(dbg & 32), allow_fast = !(dbg & 64);
-                if (p < pend) {
-                    uint32_t first;
-                    int r = find_record(q, wo, p, first);
-                    Work<TriSetup> wk = load_work<TriSetup>(q, r);
-                    int b = (int)first;
-                    float inv_nbx = 1.0f / (float)wk.nbx;
-                    for (;;) {
-                        const int by = (int)(((float)b + 0.5f) * inv_nbx), bx = b - by * wk.nbx;
-                        const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
-                        float n1, n2, n3;
-                        numerators(wk.s, x, y, n1, n2, n3);
-                        const bool live = x < wk.bx1 && y < wk.by1 &&
-                                          !(allow_rej && surely_outside(wk.s, n1, n2, n3));
-                        if (__any(live)) {   // wavefront-uniform
+                if constexpr (TS <= 32) {          // a record has at most 64 blocks: one mask word
+                    q.mask[tid] = 0;
+                    __syncthreads();
+                    // ---- coarse pass.  Exact: each numerator is monotone in X and in Y (every
+                    // rounding step is), so its extreme over the block sits on a corner; a block
+                    // goes only if all four corners are "surely outside" the SAME edge, which is
+                    // then true of every pixel in it (raster_math.h (1)).
+                    coarse_cull(q, wo, total, tid, (dbg & 4096) != 0);
+                    __syncthreads();
+                    // survivors per record -> the same two-level prefix as the block counts
+                    const uint32_t mine = (uint32_t)__popcll(q.mask[tid]);
+                    uint32_t inc = mine;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t v = __shfl_up(inc, d, 64);
+                        if (lane >= d) inc += v;
+                    }
+                    q.blk_scan[tid] = inc - mine;
+                    if (lane == 63) q.wave_blocks[wave] = inc;
+                    __syncthreads();
+#pragma unroll
+                    for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + q.wave_blocks[w];
+                    const int work = (int)wo[kThreads / 64];       // surviving blocks
+                    // the survivors are almost all partly or fully covered, so wave-wide
+                    // rejection would rarely fire: plain contiguous runs, one per lane group
+                    const int chunk = (work + 15) >> 4;
+                    int p = (tid >> 4) * chunk;
+                    const int pend = (p + chunk < work) ? (p + chunk) : work;
+                    if (p < pend) {
+                        uint32_t first;
+                        int r = find_record(q, wo, p, first);
+                        Work<TriSetup> wk = load_work<TriSetup>(q, r);
+                        float inv_nbx = 1.0f / (float)wk.nbx;
+                        // the record's survivor mask with everything before the current block cleared
+                        unsigned long long m = q.mask[r];
+                        for (uint32_t i = 0; i < first; ++i) m &= m - 1;
+                        for (;;) {
+                            const int b = __ffsll((long long)m) - 1;
+                            const int by = (int)(((float)b + 0.5f) * inv_nbx), bx = b - by * wk.nbx;
+                            const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
+                            float n1, n2, n3;
+                            numerators(wk.s, x, y, n1, n2, n3);
                             unsigned long long k;
-                            if (live && fragment_from(wk.s, wk.id, n1, n2, n3, allow_fast, k))
+                            if (x < wk.bx1 && y < wk.by1 && fragment_from(wk.s, wk.id, n1, n2, n3, allow_fast, k))
                                 lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                            if (++p >= pend) break;   // (p < pend guarantees another survivor)
+                            m &= m - 1;
+                            if (m == 0) {
+                                do { m = q.mask[++r]; } while (m == 0);
+                                wk = load_work<TriSetup>(q, r);
+                                inv_nbx = 1.0f / (float)wk.nbx;
+                            }
                         }
-                        p += 4;
-                        if (p >= pend) break;
-                        b += 4;
-                        if (b >= wk.nblk) {
-                            do {
-                                b -= wk.nblk;
-                                wk = load_work<TriSetup>(q, ++r);
-                            } while (b >= wk.nblk);
-                            inv_nbx = 1.0f / (float)wk.nbx;
+                    }
+                } else {
+                    // 64-pixel tiles (up to 256 blocks per record): no cull, dense walk
+                    const int wchunk = (total + kThreads / 64 - 1) / (kThreads / 64);
+                    int p = wave * wchunk + ((tid >> 4) & 3);
+                    const int pend = ((wave + 1) * wchunk < total) ? ((wave + 1) * wchunk) : total;
+                    if (p < pend) {
+                        uint32_t first;
+                        int r = find_record(q, wo, p, first);
+                        Work<TriSetup> wk = load_work<TriSetup>(q, r);
+                        int b = (int)first;
+                        float inv_nbx = 1.0f / (float)wk.nbx;
+                        for (;;) {
+                            const int by = (int)(((float)b + 0.5f) * inv_nbx), bx = b - by * wk.nbx;
+                            const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
+                            float n1, n2, n3;
+                            numerators(wk.s, x, y, n1, n2, n3);
+                            const bool live = x < wk.bx1 && y < wk.by1 &&
+                                              !(allow_rej && surely_outside(wk.s, n1, n2, n3));
+                            if (__any(live)) {   // wavefront-uniform
+                                unsigned long long k;
+                                if (live && fragment_from(wk.s, wk.id, n1, n2, n3, allow_fast, k))
+                                    lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                            }
+                            p += 4;
+                            if (p >= pend) break;
+                            b += 4;
+                            if (b >= wk.nblk) {
+                                do {
+                                    b -= wk.nblk;
+                                    wk = load_work<TriSetup>(q, ++r);
+                                } while (b >= wk.nblk);
+                                inv_nbx = 1.0f / (float)wk.nbx;
+                            }
                         }
                     }
                 }
