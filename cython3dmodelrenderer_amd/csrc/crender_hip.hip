@@ -23,7 +23,8 @@
 // needed for correct results and the kernels' default paths ignore them:
 //   1 no coverage work, 2 no shading (both produce WRONG images: ablation timing only),
 //   8 XCD-banded tile map, 16 never use direct bins, 32 no sign rejection, 64 no hoisted
-//   reciprocal, 128 small-record sweep for every batch, 256 invert the scatter-dispatch rule.
+//   reciprocal, 128 small-record sweep for every batch, 256 invert the scatter-dispatch rule,
+//   512 (removed), 4096 coarse pass keeps every block, 8192 large-record sweep for every batch.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ p
             for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + q.wave_blocks[w];
             const int total = (int)wo[kThreads / 64];
             const int nrec = (int)((end - base) < (uint32_t)kThreads ? (end - base) : (uint32_t)kThreads);
-            if (total < 16 * nrec || (dbg & 128)) {
+            if ((total < 16 * nrec && !(dbg & 8192)) || (dbg & 128)) {
                 // Small records: each of the 16 lane groups takes one contiguous run of blocks,
                 // so a record is set up by (almost) one group only; tight loop, plain division.
                 const int chunk = (total + 15) >> 4;
