@@ -314,6 +314,38 @@ def test_adversarial_triangles(hip, oracle, mode, tile):
     assert (f.winner >= 0).sum() > 1000
 
 
+@pytest.mark.parametrize("mode,tile", [("fused", 16), ("fused", 32), ("fused-scan", 32), ("fused", 64),
+                                       ("atomic", 0)])
+def test_adversarial_large_triangles(hip, oracle, mode, tile):
+    """The large-record sweep (coarse block cull + survivor masks) on awkward input: slivers a
+    fraction of a pixel wide but hundreds long, zero-area and collinear triangles, duplicates
+    (exact z ties), vertices far off screen, a vertex behind the camera, NaN / inf coordinates,
+    all large enough that batches average >= 16 blocks per record."""
+    rng = np.random.default_rng(123)
+    H, W = 200, 264
+    tri, col, nrm = random_soup(rng, 24, 256, size_px=(150, 700), frac_backface=0.0, margin=0.6)
+    extra = []
+    for k in range(6):                                   # slivers: two vertices almost coincide
+        t = tri[k].copy(); t[1] = t[0] + np.float32(1e-3) * (k + 1); extra.append(t)
+    t = tri[6].copy(); t[2] = t[0]; extra.append(t)       # zero area
+    t = tri[7].copy(); t[2] = (t[0] + t[1]) / 2; extra.append(t)   # collinear
+    extra += [tri[8].copy(), tri[8].copy(), tri[9].copy()]           # duplicates
+    t = tri[10].copy(); t[0, :2] *= 40; extra.append(t)   # a vertex far off screen
+    t = tri[11].copy(); t[1, 2] = -0.4; extra.append(t)   # behind the camera
+    t = tri[12].copy(); t[2, 0] = np.nan; extra.append(t)
+    t = tri[13].copy(); t[0, 1] = np.inf; extra.append(t)
+    t = tri[14].copy(); t[:, 2] = 1e-3; extra.append(t)   # very close: huge coordinates
+    extra = np.stack(extra)
+    tri = np.concatenate([tri, extra])
+    col = np.concatenate([col, rng.uniform(0, 255, extra.shape).astype(np.float32)])
+    ne = rng.standard_normal(extra.shape).astype(np.float32); ne[..., 2] = -np.abs(ne[..., 2])
+    nrm = np.concatenate([nrm, ne])
+    f = oracle_frame(oracle, tri, col, nrm, H, W)
+    got = gpu_frame(hip, tri, col, nrm, H, W, mode=mode, tile=tile)
+    compare(got, f, f"adversarial large/{mode}/{tile}")
+    assert (f.winner >= 0).mean() > 0.5
+
+
 @pytest.mark.parametrize("clear", [False, True])
 def test_no_triangles(hip, oracle, clear):
     empty = np.zeros((0, 3, 3), np.float32)
