@@ -207,7 +207,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong",      # the job is ONE frame however many GPUs share its rows
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if args.workload == "synth10m" else
             "T-Rex/bunny/cube input arrays committed under tests/golden (made from the reference's "
