@@ -8,9 +8,13 @@ Default workload: T-Rex.obj at 1024x1024, fov 45 (configs[1], the README benchma
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is sharded into
-row strips, each rank rasterizes its strip and the strips are all-gathered with RCCL —
-one frame is produced cooperatively, so scaling is "strong".
+N > 1 (launched by torch.distributed.run, one rank per GPU), two modes:
+  --mode frames (default)  every rank renders its own full frames, no collective in the data
+                           path: "weak" scaling, value = frames of all ranks per second;
+  --mode strips            north_star's layout: ONE frame per step, sharded into row strips, the
+                           strips all-gathered with RCCL: "strong" scaling.  The all-gather moves
+                           28 B/pixel to every rank, which costs more than rendering the frame on
+                           one GPU, hence not the default.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the raster kernel against HBM bandwidth
 with the algorithmic bytes of SURVEY.md section 8d (108 B per triangle read once + 28 B per
@@ -109,6 +113,11 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the next frame's bin pass with this frame's raster pass")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
+    ap.add_argument("--mode", default="frames", choices=["frames", "strips"],
+                    help="N>1: 'frames' (default) = every rank renders its own full frame per step, no "
+                         "collective in the data path (weak scaling); 'strips' = ONE frame per step, "
+                         "row strips + RCCL all-gather of the planes (north_star's layout; strong "
+                         "scaling).  See DESIGN.md section 5 for why frames is the default.")
     args = ap.parse_args()
 
     import torch
@@ -135,14 +144,15 @@ def main():
     if args.max_triangles >= 0:
         tri, col, nrm = tri[:args.max_triangles], col[:args.max_triangles], nrm[:args.max_triangles]
     T = int(tri.shape[0])
-    y0, y1 = D.strip_rows(H, world, rank)
+    strips = world > 1 and args.mode == "strips"
+    y0, y1 = D.strip_rows(H, world, rank) if strips else (0, H)
     filler = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile,
-                                       row_strip=(y0, y1) if world > 1 else None,
+                                       row_strip=(y0, y1) if strips else None,
                                        pipeline=not args.no_pipeline)
 
     def step(pipelined=True):
         filler.render_frame(pipelined=pipelined)
-        if world > 1 and not args.no_gather:
+        if strips and not args.no_gather:
             filler.join()            # the collective runs on this stream, the frame on the pipeline's
             D.all_gather_strips([filler.z_buffer, filler.color_buffer, filler.normals_buffer],
                                 H, rank, world)
@@ -198,7 +208,8 @@ def main():
         elapsed, raster_ms, bin_ms = (float(v) for v in t.cpu())
 
     if rank == 0:
-        fps = args.steps / elapsed
+        frames_per_step = 1 if (world == 1 or strips) else world
+        fps = frames_per_step * args.steps / elapsed
         rows = y1 - y0                               # this rank's strip (ranks are symmetric)
         abytes = algorithmic_bytes(T, rows, W)
         achieved = abytes / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
@@ -207,18 +218,23 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",      # the job is ONE frame however many GPUs share its rows
+            # strips: the job is ONE frame however many GPUs share its rows; frames: one per rank
+            "scaling": "strong" if (world == 1 or strips) else "weak",
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if args.workload == "synth10m" else
             "T-Rex/bunny/cube input arrays committed under tests/golden (made from the reference's "
             ".obj assets); no dataset download",
             "config": {"workload": args.workload, "triangles": T, "height": H, "width": W,
-                       "fov": fov, "row_strips": world, "tile": filler.tile or "auto",
+                       "fov": fov, "row_strips": world if strips else 1,
+                       "multi_gpu": ("single GPU" if world == 1 else
+                                     "row strips + RCCL all-gather of the three planes" if strips else
+                                     "independent full frames per rank, no collective"),
+                       "tile": filler.tile or "auto",
                        "frame": "clear + project + rasterize, model resident in HBM",
                        "pipelined": (False if args.no_pipeline else
                                      "swap chain of 3 (triple buffering): frames in flight render into "
                                      "separate framebuffer sets on separate streams, each frame complete"),
-                       "all_gather": bool(world > 1 and not args.no_gather)},
+                       "all_gather": bool(strips and not args.no_gather)},
             "mtris_per_sec": T * fps / 1e6,
             "frame_algorithmic_bytes": algorithmic_bytes(T, H, W),
             "whole_frame_gbps": algorithmic_bytes(T, H, W) * fps / 1e9,
