@@ -219,7 +219,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             # strips: the job is ONE frame however many GPUs share its rows; frames: one per rank
-            "scaling": "strong" if (world == 1 or strips) else "weak",
+            "scaling": "strong" if args.mode == "strips" else "weak",
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if args.workload == "synth10m" else
             "T-Rex/bunny/cube input arrays committed under tests/golden (made from the reference's "
