@@ -1,6 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel trace + HBM counters for one workload.
 #   scripts/profile_gpu.sh <workload> <steps> [extra bench args]
+# Profiled single-stream (--no-pipeline) so a kernel's duration is its own: with the swap chain
+# three frames overlap and every launch looks ~3x longer than it is.
 # Counters are collected in their own passes (FETCH_SIZE and WRITE_SIZE do not fit together,
 # MI355X_MICROARCH.md "rocprofv3 PMC slots"); no trace domain is combined with --pmc.
 set -u
@@ -9,7 +11,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$WL
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="$REPO/bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline $*"
+ARGS="$REPO/bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline --no-pipeline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
