@@ -45,6 +45,10 @@ print("end   (since its XCD's first tile): p50 %d p90 %d max %d" % tuple(np.perc
 for name, d in (("init(start->ready)", ready - start), ("sweeps(ready->swept)", swept - ready), ("resolve(swept->end)", end - swept), ("total", end - start)):
     act = n > 0
     print(f"{name:22s} all: p50 {np.percentile(d,50):8.0f} p90 {np.percentile(d,90):8.0f} max {d.max():8d} | active tiles: p50 {np.percentile(d[act],50) if act.any() else 0:8.0f} p90 {np.percentile(d[act],90) if act.any() else 0:8.0f} max {d[act].max() if act.any() else 0:8d}")
+ld, qd = s[:, 5] - base, s[:, 6] - base
+act = n > 0
+for name, d in (("  ready->loads landed", ld - ready), ("  loads->queue built", qd - ld), ("  queue->swept (1st batch sweep + rest)", swept - qd)):
+    print(f"{name:40s} active tiles: p50 {np.percentile(d[act],50):8.0f} p90 {np.percentile(d[act],90):8.0f} max {d[act].max():8d}")
 order = np.argsort(-(end - start))[:12]
 print("slowest tiles: tile list_len start init sweeps resolve end xcc/hwid")
 for i in order:
