@@ -1,1 +1,9 @@
-from .model import Model  # noqa: F401
+"""Input side of the rasterizer: the triangle-mesh container whose three ``*_by_triangles``
+arrays ``AdvancedPixelBufferFiller.render_model`` reads (the reference's
+``crender.cy.data_structures``; its ``Buffer`` wrapper is not needed here: framebuffers are
+torch tensors / numpy mirrors)."""
+from . import model as _model
+
+Model = _model.Model
+
+__all__ = ["Model"]

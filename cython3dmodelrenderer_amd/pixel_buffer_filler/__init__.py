@@ -1,1 +1,7 @@
-from .advanced_pixel_buffer_filler import AdvancedPixelBufferFiller  # noqa: F401
+"""The hot path: ``AdvancedPixelBufferFiller`` backed by the HIP library (the reference's
+``crender.cy.pixel_buffer_filler``; its wireframe filler is out of scope)."""
+from . import advanced_pixel_buffer_filler as _filler
+
+AdvancedPixelBufferFiller = _filler.AdvancedPixelBufferFiller
+
+__all__ = ["AdvancedPixelBufferFiller"]

@@ -82,8 +82,9 @@ class _FramePipeline:
         self.max_T = max(int(T), 1)
         self.handle = C.c_void_p()
         arr = (C.c_void_p * self.depth)(*[p.value for p in self.plans])
-        _capi.check(self.lib.crender_pipeline_create(C.byref(self.handle), arr, self.depth),
-                    "crender_pipeline_create")
+        with torch.cuda.device(self.device):       # the pipeline's streams live on this device
+            _capi.check(self.lib.crender_pipeline_create(C.byref(self.handle), arr, self.depth),
+                        "crender_pipeline_create")
         # framebuffer sets of the swap chain: the filler's own buffers and copies of them
         front = (filler.z_buffer, filler.color_buffer, filler.normals_buffer, filler.winner_buffer)
         self.sets = [front] + [tuple(None if t is None else t.clone() for t in front)
@@ -113,8 +114,13 @@ class _FramePipeline:
                                 None if w is None else w.data_ptr(),
                                 _capi.FUSED_CLEAR | filler._extra_flags))
             self._args = (filler._inputs, per_set)
-        rc = self.lib.crender_pipeline_frame(*self._args[1][self.k],
-                                             torch.cuda.current_stream(self.device).cuda_stream)
+        args = self._args[1][self.k]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if torch.cuda.current_device() == self.device.index:
+            rc = self.lib.crender_pipeline_frame(*args, stream)
+        else:                              # the library launches on the calling thread's device
+            with torch.cuda.device(self.device):
+                rc = self.lib.crender_pipeline_frame(*args, stream)
         if rc:
             _capi.check(rc, "crender_pipeline_frame")
         # the filler's buffers are now this frame's
