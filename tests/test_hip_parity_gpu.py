@@ -346,6 +346,46 @@ def test_adversarial_large_triangles(hip, oracle, mode, tile):
     assert (f.winner >= 0).mean() > 0.5
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_random_configurations(hip, oracle, seed):
+    """Seeded fuzz over everything at once: frame shape, camera, triangle count and size mix,
+    tile size, binning path, row strips, compositing on top of a previous frame, fused clear."""
+    rng = np.random.default_rng(1000 + seed)
+    H = int(rng.integers(1, 400)); W = int(rng.integers(1, 400))
+    if seed % 5 == 0:
+        H, W = int(rng.integers(500, 1100)), int(rng.integers(500, 1100))
+    fov = float(rng.choice([30.0, 45.0, 60.0, 90.0, 110.0]))
+    T = int(rng.choice([0, 1, 2, 17, 300, 2500, 9000]))
+    lo = float(rng.choice([0.2, 1.0, 4.0])); hi = lo * float(rng.choice([2.0, 10.0, 80.0]))
+    tri, col, nrm = random_soup(rng, T, max(H, W, 32), size_px=(lo, hi),
+                                margin=float(rng.choice([0.0, 0.5, 1.5])))
+    tri[..., :2] *= np.float32(2.4142137 * np.tan(np.radians(fov / 2)))
+    tile = int(rng.choice([0, 16, 32, 64]))
+    mode = str(rng.choice(["fused", "fused-scan", "split", "atomic"]))
+    clear = bool(rng.integers(0, 2))
+    prior = None
+    if rng.integers(0, 2):
+        prior = (rng.uniform(0.2, 3.0, (H, W)).astype(np.float32),
+                 rng.uniform(0, 255, (H, W, 3)).astype(np.float32),
+                 rng.standard_normal((H, W, 3)).astype(np.float32))
+    cuts = sorted(set(int(v) for v in rng.integers(0, H + 1, int(rng.integers(0, 4)))) | {0, H})
+    strips = [(a, b) for a, b in zip(cuts, cuts[1:]) if b > a]
+    zn, zf = 0.1, 1000.0
+    f = oracle.OracleFiller(H, W, fov=fov, z_near=zn, z_far=zf)
+    if prior is not None and not clear:
+        f.z_buffer[...], f.color_buffer[...], f.normals_buffer[...] = prior
+    for (y0, y1) in strips:
+        f.render_arrays(tri, col, nrm, y0=y0, y1=y1)
+    got = gpu_frame(hip, tri, col, nrm, H, W, fov=fov, mode=mode, tile=tile, strips=strips,
+                    prior=prior, clear=clear)
+    what = f"fuzz {seed}: {H}x{W} fov {fov} T {T} px ({lo},{hi}) tile {tile} {mode} clear {clear} strips {strips}"
+    assert_bit_equal(got[0], f.z_buffer, what + ": z")
+    assert_bit_equal(got[1], f.color_buffer, what + ": colour")
+    assert_bit_equal(got[2], f.normals_buffer, what + ": normal")
+    touched = f.winner >= 0
+    assert_bit_equal(got[3][touched], f.winner[touched], what + ": winner")
+
+
 @pytest.mark.parametrize("clear", [False, True])
 def test_no_triangles(hip, oracle, clear):
     empty = np.zeros((0, 3, 3), np.float32)
