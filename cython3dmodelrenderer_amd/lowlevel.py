@@ -143,6 +143,30 @@ def render_model(plan, tri, col, nrm, P, fb, clear=False, direct_bins=True):
             _flags(clear, direct_bins), _stream(fb.device)), "crender_render_model")
 
 
+def prepare(plan, tri, nrm, P, stream=None, direct_bins=True):
+    """First half of render_model: K1 + binning into the plan (``P=None``: ``tri`` is already
+    projected).  ``stream``: a torch.cuda.Stream, default the current one."""
+    _chk_f32(tri, "tri", (3, 3))
+    _chk_f32(nrm, "nrm", (3, 3))
+    s = C.c_void_p((stream or torch.cuda.current_stream(plan.device)).cuda_stream)
+    with torch.cuda.device(plan.device):
+        _capi.check(plan._lib.crender_prepare(plan.handle, tri.data_ptr(), nrm.data_ptr(), tri.shape[0],
+                                              None if P is None else _capi.f32_16(P),
+                                              _flags(False, direct_bins), s), "crender_prepare")
+
+
+def draw(plan, col, nrm, T, fb, proj=None, clear=False, stream=None, direct_bins=True):
+    """Second half of render_model: K2 from the plan's bins (``proj=None``: the vertices that
+    ``prepare`` projected into the plan)."""
+    s = C.c_void_p((stream or torch.cuda.current_stream(fb.device)).cuda_stream)
+    with torch.cuda.device(fb.device):
+        _capi.check(plan._lib.crender_draw(
+            plan.handle, None if proj is None else proj.data_ptr(), col.data_ptr(), nrm.data_ptr(), int(T),
+            fb.z.data_ptr(), fb.color.data_ptr(), fb.normals.data_ptr(),
+            fb.winner.data_ptr() if fb.winner is not None else None,
+            _flags(clear, direct_bins), s), "crender_draw")
+
+
 def raster_atomic(proj, col, nrm, fb, y0=0, y1=None, clear=False, keys=None):
     """K2 by the independent global-atomic path (cross-check implementation)."""
     lib = _capi.load()

@@ -438,6 +438,45 @@ def test_direct_bins_fall_back_when_a_tile_list_overflows(hip, oracle):
     compare(tuple(fb.numpy()) + (None,), f, "after direct-bin fallback")
 
 
+@pytest.mark.parametrize("direct", [True, False])
+def test_prepare_and_draw_halves(hip, oracle, direct):
+    """crender_prepare + crender_draw == crender_render_model, also with the two halves on
+    different streams ordered by an event, and with pre-projected vertices (P16 == NULL)."""
+    import torch
+    tri, col, nrm = scene("trex_inputs.npz")
+    H, W = 240, 320
+    f = oracle_frame(oracle, tri, col, nrm, H, W)
+    P = hip.projection_matrix(45.0, 0.1, 1000.0, H, W)
+    t, c, n = _dev(tri), _dev(col), _dev(nrm)
+    # same stream
+    fb = hip.FrameBuffers(H, W)
+    plan = hip.Plan(H, W, len(tri))
+    hip.prepare(plan, t, n, P, direct_bins=direct)
+    hip.draw(plan, c, n, len(tri), fb, direct_bins=direct)
+    assert plan.last_frame_direct() == direct
+    compare(tuple(fb.numpy()) + (None,), f, "prepare + draw")
+    # two streams, ordered by an event; fused clear over junk
+    fb2 = hip.FrameBuffers(H, W)
+    fb2.z.fill_(0.5); fb2.color.fill_(7.0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    hip.prepare(plan, t, n, P, stream=side, direct_bins=direct)
+    done = torch.cuda.Event(); done.record(side)
+    torch.cuda.current_stream().wait_event(done)
+    hip.draw(plan, c, n, len(tri), fb2, clear=True, direct_bins=direct)
+    compare(tuple(fb2.numpy()) + (None,), f, "prepare on a side stream")
+    # already projected vertices
+    proj = hip.project(t, P, W, H)
+    fb3 = hip.FrameBuffers(H, W)
+    hip.prepare(plan, proj, n, None, direct_bins=direct)
+    hip.draw(plan, c, n, len(tri), fb3, proj=proj, direct_bins=direct)
+    compare(tuple(fb3.numpy()) + (None,), f, "pre-projected halves")
+    # a draw whose T does not match the prepared frame is refused
+    from cython3dmodelrenderer_amd import _capi
+    with pytest.raises(_capi.CrenderError):
+        hip.draw(plan, c, n, len(tri) - 1, fb3, proj=proj)
+
+
 def test_c_abi_argument_errors(hip):
     import ctypes as C
     from cython3dmodelrenderer_amd import _capi
