@@ -69,6 +69,7 @@ int fail_hip(hipError_t e, const char *where)
     } while (0)
 
 constexpr int kThreads = 256;           // 4 wavefronts per workgroup
+constexpr uint32_t kPixelPathRecords = 8;   // k_raster<16>: batches this short go pixel-parallel
 constexpr uint32_t kNoTiles = 0xFFFFFFFFu;
 
 // Strip geometry shared by the binning and raster kernels.
@@ -742,6 +743,44 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ p
 #ifdef CRENDER_STAMPS
         if (base == beg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CR_STAMP(5); }
 #endif
+        if constexpr (TS == 16) {
+            // Short batch on a 16-pixel tile: one PIXEL per thread, every thread walks the
+            // records (LDS broadcast reads), the running minimum stays in a register — no
+            // block scan, no record search, no LDS atomics.  A wavefront (4 rows of the tile)
+            // skips a record whose box misses its rows.
+            const uint32_t left = end - base;
+            const uint32_t pix_max = (dbg >> 16) & 0xFF ? (uint32_t)((dbg >> 16) & 0xFF) - 1u : kPixelPathRecords;
+            if (left <= pix_max) {
+                __syncthreads();
+                if (tid < (int)left) {
+                    q.x0[tid] = cur_t.x0; q.y0[tid] = cur_t.y0; q.z0[tid] = cur_t.z0;
+                    q.x1[tid] = cur_t.x1; q.y1[tid] = cur_t.y1; q.z1[tid] = cur_t.z1;
+                    q.x2[tid] = cur_t.x2; q.y2[tid] = cur_t.y2; q.z2[tid] = cur_t.z2;
+                    q.tri[tid] = cur_id;
+                    q.box_xy[tid] = box_xy;
+                    q.box_wh[tid] = box_wh;
+                }
+                __syncthreads();
+                const int px = X0 + (tid & 15), py = Y0 + (tid >> 4);
+                unsigned long long best = key[tid];
+                for (uint32_t r = 0; r < left; ++r) {
+                    const uint32_t wh = q.box_wh[r];
+                    if (wh == 0) continue;
+                    const uint32_t xy = q.box_xy[r];
+                    const int bx0 = (int)(xy & 0xFFFF), by0 = (int)(xy >> 16);
+                    const bool in = px >= bx0 && px < bx0 + (int)(wh & 0xFFFF) &&
+                                    py >= by0 && py < by0 + (int)(wh >> 16);
+                    if (!__any(in)) continue;
+                    const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
+                                   q.x2[r], q.y2[r], q.z2[r]};
+                    unsigned long long k;
+                    if (in && fragment(t, q.tri[r], px, py, k) && k < best) best = k;
+                }
+                key[tid] = best;
+                cur_ok = false;
+                continue;   // (this was the list's last batch)
+            }
+        }
         // wave-inclusive scan of the block counts
         const uint32_t my_blocks = (uint32_t)blocks_of(box_wh);
         uint32_t incl = my_blocks;
