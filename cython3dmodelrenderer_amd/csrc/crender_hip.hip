@@ -24,7 +24,9 @@
 //   1 no coverage work, 2 no shading (both produce WRONG images: ablation timing only),
 //   8 XCD-banded tile map, 16 never use direct bins, 32 no sign rejection, 64 no hoisted
 //   reciprocal, 128 small-record sweep for every batch, 256 invert the scatter-dispatch rule,
-//   512 (removed), 4096 coarse pass keeps every block, 8192 large-record sweep for every batch.
+//   4096 coarse pass keeps every block, 8192 large-record sweep for every batch (32/64-pixel
+//   tiles), bits 16..23 = n + 1: pixel-parallel path of 16-pixel tiles for batches <= n records
+//   (n = 0 disables it; default kPixelPathRecords).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -69,6 +71,12 @@ int fail_hip(hipError_t e, const char *where)
     } while (0)
 
 constexpr int kThreads = 256;           // 4 wavefronts per workgroup
+#ifndef CR_WPE16
+// Waves per SIMD asked of k_raster<16>: 6 caps it at 80 VGPRs (one spilled, 8 B of scratch)
+// instead of 92; with three frames in flight T-Rex 1024^2 gains 7 % (67.8k -> 72.7k fps), a
+// lone frame loses 1 % (r01 A/B, same box).  The 32/64-pixel kernels spill badly under a cap.
+#define CR_WPE16 6
+#endif
 constexpr uint32_t kPixelPathRecords = 8;   // k_raster<16>: batches this short go pixel-parallel
 constexpr uint32_t kNoTiles = 0xFFFFFFFFu;
 
@@ -636,19 +644,18 @@ __device__ unsigned long long *g_stamps = nullptr;
 #define CR_STAMP(slot) do { } while (0)
 #endif
 
-// No occupancy bound is declared: capping at 80 VGPRs (6 wavefronts per SIMD) was 3-5 % faster
-// on the fill-heavy workloads but 5 % slower on T-Rex 1024^2, and its 32 B/lane of scratch shows
-// up as +5..+25 % WRITE_SIZE (r01 A/B, same box).  92-98 VGPRs, no scratch.
+// Register budget: the 32/64-pixel kernels declare no occupancy bound — capping them at 80
+// VGPRs (6 wavefronts per SIMD) was 3-5 % faster on the fill-heavy workloads, but its 32 B/lane
+// of scratch shows up as +5..+25 % WRITE_SIZE (r01 A/B, same box); they use 94-98 VGPRs, no
+// scratch.  The 16-pixel kernel has no large-record path and fits 80 with one spilled register
+// (CR_WPE16 above).
 template <int TS, bool CLEAR>
-__global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ proj,
-                                                     const float *__restrict__ col,
-                                                     const float *__restrict__ nrm,
-                                                     const uint32_t *__restrict__ offs,
-                                                     uint32_t *__restrict__ cursor,
-                                                     const uint32_t *__restrict__ entries,
-                                                     uint32_t capacity, float *__restrict__ zb,
-                                                     float *__restrict__ cb, float *__restrict__ nb,
-                                                     int32_t *__restrict__ win, Geom G, int dbg)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? CR_WPE16 : 1)))
+void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
+              const float *__restrict__ nrm, const uint32_t *__restrict__ offs,
+              uint32_t *__restrict__ cursor, const uint32_t *__restrict__ entries, uint32_t capacity,
+              float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
+              int32_t *__restrict__ win, Geom G, int dbg)
 {
     __shared__ unsigned long long key[TS * TS];
     __shared__ WorkQueue q;
@@ -822,7 +829,8 @@ __global__ __launch_bounds__(kThreads) void k_raster(const float *__restrict__ p
             for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + q.wave_blocks[w];
             const int total = (int)wo[kThreads / 64];
             const int nrec = (int)((end - base) < (uint32_t)kThreads ? (end - base) : (uint32_t)kThreads);
-            if ((total < 16 * nrec && !(dbg & 8192)) || (dbg & 128)) {
+            // (a 16-pixel tile holds 16 blocks: its records are never large)
+            if (TS == 16 || (total < 16 * nrec && !(dbg & 8192)) || (dbg & 128)) {
                 // Small records: each of the 16 lane groups takes one contiguous run of blocks,
                 // so a record is set up by (almost) one group only; tight loop, plain division.
                 const int chunk = (total + 15) >> 4;
