@@ -113,6 +113,11 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the next frame's bin pass with this frame's raster pass")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1: 'nccl' (= RCCL, one rank per GPU).  'gloo' is a rehearsal of the "
+                         "launch contract on a box with fewer GPUs than ranks: ranks share devices "
+                         "(LOCAL_RANK modulo the device count) and host-side collectives carry the "
+                         "timings; --mode strips then needs --no-gather")
     ap.add_argument("--mode", default="frames", choices=["frames", "strips"],
                     help="N>1: 'frames' (default) = every rank renders its own full frame per step, no "
                          "collective in the data path (weak scaling); 'strips' = ONE frame per step, "
@@ -134,11 +139,18 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N "
                              "--master-addr 127.0.0.1 bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.backend == "gloo":
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            if args.mode == "strips" and not args.no_gather:
+                raise SystemExit("--backend gloo cannot all-gather device planes: add --no-gather")
+            dist.init_process_group("gloo")
 
     tri, col, nrm, (H, W), fov = scenes.scene(args.workload, synth_T=args.synth_triangles)
     if args.max_triangles >= 0:
@@ -208,7 +220,8 @@ def main():
     assert need <= cap, "bin lists overflowed inside the timing pass"
 
     if world > 1:
-        t = torch.tensor([elapsed, raster_ms, bin_ms], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, raster_ms, bin_ms], dtype=torch.float64,
+                         device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, raster_ms, bin_ms = (float(v) for v in t.cpu())
 
