@@ -24,8 +24,8 @@
 //   1 no coverage work, 2 no shading (both produce WRONG images: ablation timing only),
 //   8 XCD-banded tile map, 16 never use direct bins, 32 no sign rejection, 64 no hoisted
 //   reciprocal, 128 small-record sweep for every batch, 256 invert the scatter-dispatch rule,
-//   4096 coarse pass keeps every block, 8192 large-record sweep for every batch (32/64-pixel
-//   tiles), bits 16..23 = n + 1: pixel-parallel path of 16-pixel tiles for batches <= n records
+//   512 no row rotation of the tile map, 4096 coarse pass keeps every block, 8192 large-record
+//   sweep for every batch (32/64-pixel tiles), bits 16..23 = n + 1: pixel-parallel path of 16-pixel tiles for batches <= n records
 //   (n = 0 disables it; default kPixelPathRecords).
 #include <hip/hip_runtime.h>
 
@@ -632,13 +632,14 @@ CR_DEV void coarse_cull(WorkQueue &q, const uint32_t *wo, int total, int tid,
 }
 
 #ifdef CRENDER_STAMPS
-// Diagnostic build only: per-tile phase timestamps (s_memtime) written to a buffer of their
+// Diagnostic build only: per-tile phase timestamps (s_memrealtime, 100 MHz, one clock for the
+// whole device — s_memtime has a base per XCD / clock domain) written to a buffer of their
 // own that no kernel reads.  8 words per tile: t_start, t_ready, t_swept, t_end, list length,
-// hw id, batches, unused.
+// (unused), (unused), XCC id.
 __device__ unsigned long long *g_stamps = nullptr;
 #define CR_STAMP(slot)                                                             \
     do {                                                                           \
-        if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)tile * 8 + (slot)] = __builtin_readcyclecounter(); \
+        if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)tile * 8 + (slot)] = wall_clock64(); \
     } while (0)
 #else
 #define CR_STAMP(slot) do { } while (0)
@@ -667,7 +668,21 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
     // (T-Rex 1024^2: 24.7 vs 29.1 us), so the scatter starts at 32768 tiles.
     if ((G.ntiles >= 32768) != ((dbg & 256) != 0))
         tile = (int)(((unsigned long long)blockIdx.x * (unsigned)G.tile_stride) % (unsigned)G.ntiles);
-    const int tx = tile % G.ntx, ty = tile / G.ntx;
+    int tx = tile % G.ntx;
+    const int ty = tile / G.ntx;
+    // Workgroup b runs on XCD b % 8 and, there, on shader engine (b / 8) % 4, and the dispatcher
+    // places workgroups strictly in order.  With a tile row that is a multiple of 32 tiles a
+    // tile COLUMN would always meet the same (XCD, engine) pair: the pairs that own the columns
+    // under the model fill up with long-lived workgroups and stall the whole dispatch while a
+    // third of the chip's workgroup slots stand free (in-kernel timeline, scripts/stamps.py:
+    // ~900 of T-Rex's 1140 covered tiles in flight, the rest trickling in).  Rotating row ty
+    // by 9 * ty columns walks every pair through every column: all covered tiles are in flight
+    // after 3 us (T-Rex 1024^2 raster 24.0 -> 21.6 us, 73.3k -> 79.2k frames/s; the larger
+    // frames gain 0-2 %).  CRENDER_DEBUG bit 512 turns it off.
+    if (!(dbg & 512)) {
+        tx = (tx + 9 * ty) % G.ntx;
+        tile = ty * G.ntx + tx;
+    }
     const int X0 = tx * TS, Y0 = G.y0 + ty * TS;
     const int X1 = (X0 + TS < G.W) ? (X0 + TS) : G.W;
     const int Y1 = (Y0 + TS < G.y1) ? (Y0 + TS) : G.y1;
@@ -675,6 +690,10 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
     const int lane = tid & 63, wave = tid >> 6;
 
     CR_STAMP(0);
+#ifdef CRENDER_STAMPS
+    // XCC_ID (hwreg 20, bits 0..3)
+    if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)tile * 8 + 7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+#endif
     // the tile's triangle list: a run of the scanned bin array, or (direct bins, offs == null)
     // a fixed-capacity slab whose fill count k_setup left in cursor[tile]
     uint32_t beg, end;
@@ -768,6 +787,9 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                     q.box_wh[tid] = box_wh;
                 }
                 __syncthreads();
+#ifdef CRENDER_STAMPS
+                if (base == beg) CR_STAMP(6);
+#endif
                 const int px = X0 + (tid & 15), py = Y0 + (tid >> 4);
                 unsigned long long best = key[tid];
                 for (uint32_t r = 0; r < left; ++r) {

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Diagnostic: builds a -DCRENDER_STAMPS copy of the library, renders one workload and prints
-per-tile phase durations of k_raster (shader clocks from s_memtime).  Never used for timing
+per-tile phase durations of k_raster (s_memrealtime, 10 ns ticks, printed in ns).  Never used for timing
 claims: the stamped build is slower; only the SHARES are read."""
 import ctypes as C, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from cython3dmodelrenderer_amd import _build
 dbg_lib = "/tmp/libcrender_hip_stamps.so"
-subprocess.check_call([_build._hipcc()] + _build.HIPCC_FLAGS + ["-DCRENDER_STAMPS", "-o", dbg_lib,
+subprocess.check_call([_build._hipcc()] + _build.HIPCC_FLAGS + ["-DCRENDER_STAMPS"] + os.environ.get("STAMPS_DEFS", "").split() + ["-o", dbg_lib,
                        os.path.join(_build.SRC_DIR, "crender_hip.hip")], stderr=subprocess.DEVNULL)
 _build.LIB_PATH = dbg_lib
 import torch
@@ -18,7 +18,7 @@ tri, col, nrm, (H, W), fov = scenes.scene(wl)
 L = _capi.load()
 f = AdvancedPixelBufferFiller(H, W, fov=fov, tile=tile)
 f.render_arrays(tri, col, nrm, clear=True); f.synchronize()
-ts = tile or (32 if H * W <= 2048 * 2048 else 64)
+ts = tile or (16 if H * W <= 1024 * 1024 else 32)   # pick_tile() of crender_hip.hip
 nt = ((W + ts - 1) // ts) * ((H + ts - 1) // ts)
 buf = torch.zeros(nt * 8, dtype=torch.int64, device="cuda:0")
 L.crender_debug_set_stamps.argtypes = [C.c_void_p]; L.crender_debug_set_stamps.restype = C.c_int
@@ -28,17 +28,15 @@ assert L.crender_debug_set_stamps(buf.data_ptr()) == 0
 f.render_frame(); f.synchronize()
 L.crender_debug_set_stamps(None)
 s = buf.cpu().numpy().reshape(nt, 8).astype(np.int64)
-# each XCD has its own clock base: cluster the start stamps and rebase per cluster
-order0 = np.argsort(s[:, 0]); base = np.zeros(nt, np.int64); cur = s[order0[0], 0]
-prev = cur
-for i in order0:
-    if s[i, 0] - prev > 10_000_000: cur = s[i, 0]
-    base[i] = cur; prev = s[i, 0]
+# stamps are s_memrealtime ticks (100 MHz, device-wide); shown in ns since the first tile's start
+for k in (0, 1, 2, 3, 5, 6):
+    s[:, k] *= 10
+base = np.full(nt, s[:, 0].min(), np.int64)
 empty = s[:, 1] == 0            # empty tiles take the fast path and only stamp start / end
 s[empty, 1] = s[empty, 0]; s[empty, 2] = s[empty, 0]
 start, ready, swept, end, n = s[:, 0] - base, s[:, 1] - base, s[:, 2] - base, s[:, 3] - base, s[:, 4]
-print("XCD clock clusters:", len(set(base.tolist())))
-print(f"{wl} tile={ts} tiles={nt} kernel span {end.max()} clk; clocks are s_memtime ticks")
+print("XCDs:", len(set(s[:, 7].tolist())))
+print(f"{wl} tile={ts} tiles={nt} kernel span {end.max()} ns")
 print("start (since its XCD's first tile): p50 %d p90 %d max %d | active tiles p50 %d p90 %d max %d" % (
     tuple(np.percentile(start, [50, 90, 100])) + tuple(np.percentile(start[n > 0], [50, 90, 100]))))
 print("end   (since its XCD's first tile): p50 %d p90 %d max %d" % tuple(np.percentile(end, [50, 90, 100])))
@@ -59,3 +57,11 @@ print("last-finishing tiles:", [(int(i), int(n[i]), int(start[i]), int(end[i])) 
 for lo, hi in ((1, 8), (8, 32), (32, 64), (64, 128), (128, 256), (256, 512), (512, 100000)):
     m = (n >= lo) & (n < hi)
     if m.any(): print(f"list [{lo},{hi}): tiles {m.sum():5d} sweeps p50 {np.percentile((swept-ready)[m],50):8.0f} max {(swept-ready)[m].max():8d}  resolve p50 {np.percentile((end-swept)[m],50):8.0f}")
+# timeline: tiles in flight per slice of the kernel span (active = has a list, empty = fast path)
+span = int(end.max()); nb = 24; edges = np.linspace(0, span, nb + 1)
+print("timeline (slice start ns: active tiles in flight, empty tiles in flight, tiles started)")
+for b in range(nb):
+    lo, hi = edges[b], edges[b + 1]
+    infl = (start < hi) & (end > lo)
+    print("%8d: active %5d empty %5d started %5d" % (lo, (infl & act).sum(), (infl & ~act).sum(),
+                                                      ((start >= lo) & (start < hi)).sum()))
