@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the next frame's bin pass with this frame's raster pass")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
+    ap.add_argument("--pipeline-depth", type=int, default=0,
+                    help="frames in flight (swap-chain depth); 0 = the filler's choice")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1: 'nccl' (= RCCL, one rank per GPU).  'gloo' is a rehearsal of the "
                          "launch contract on a box with fewer GPUs than ranks: ranks share devices "
@@ -125,6 +127,9 @@ def main():
                          "scaling).  See DESIGN.md section 5 for why frames is the default.")
     args = ap.parse_args()
 
+    # more hardware queues than the runtime's default of 4, so that four streams of the swap
+    # chain plus torch's own do not share one (read by the HIP runtime when it starts)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     from cython3dmodelrenderer_amd import distributed as D
@@ -160,7 +165,8 @@ def main():
     y0, y1 = D.strip_rows(H, world, rank) if strips else (0, H)
     filler = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile,
                                        row_strip=(y0, y1) if strips else None,
-                                       pipeline=not args.no_pipeline)
+                                       pipeline=not args.no_pipeline,
+                                       pipeline_depth=args.pipeline_depth)
 
     def step(pipelined=True):
         filler.render_frame(pipelined=pipelined)
@@ -261,7 +267,8 @@ def main():
                        "tile": filler.tile or "auto",
                        "frame": "clear + project + rasterize, model resident in HBM",
                        "pipelined": (False if args.no_pipeline else
-                                     "swap chain of 3 (triple buffering): frames in flight render into "
+                                     f"swap chain of {filler._pipeline_depth} (GPU_MAX_HW_QUEUES="
+                                     f"{os.environ.get('GPU_MAX_HW_QUEUES')}): frames in flight render into "
                                      "separate framebuffer sets on separate streams, each frame complete"),
                        "all_gather": bool(strips and not args.no_gather)},
             "mtris_per_sec": T * fps / 1e6,

@@ -42,6 +42,8 @@ SIGNATURES = {
     "crender_pipeline_destroy": (None, [_vp]),
     "crender_pipeline_frame": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32p, _vp, _vp, _vp, _vp, _u32, _vp]),
     "crender_pipeline_join": (_i32, [_vp, _vp]),
+    "crender_pipeline_bind": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _f32p, _vp, _vp, _vp, _vp, _u32]),
+    "crender_pipeline_submit": (_i32, [_vp, _vp]),
     "crender_atomic_scratch_bytes": (_sz, [_i32, _i32]),
     "crender_raster_atomic": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                      _u32, _vp, _vp]),

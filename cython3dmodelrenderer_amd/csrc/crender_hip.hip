@@ -1245,6 +1245,15 @@ struct crender_pipeline {
     int64_t last_T = -1;
     hipStream_t last_caller = nullptr;
     bool synced = false;
+    struct Bound {   // crender_pipeline_bind
+        bool set = false, has_P = false;
+        const float *tri = nullptr, *col = nullptr, *nrm = nullptr;
+        int64_t T = 0;
+        float P[16] = {};
+        float *z = nullptr, *color = nullptr, *normal = nullptr;
+        int32_t *winner = nullptr;
+        unsigned flags = 0;
+    } bound[kMaxPipelineDepth];
 };
 
 namespace {
@@ -1712,6 +1721,29 @@ int crender_pipeline_frame(crender_pipeline *p, const float *d_tri, const float 
     if (rc != CRENDER_OK) return rc;
     p->n++;
     return CRENDER_OK;
+}
+
+int crender_pipeline_bind(crender_pipeline *p, int slot, const float *d_tri, const float *d_col,
+                          const float *d_nrm, int64_t T, const float *P16, float *d_z, float *d_color,
+                          float *d_normal, int32_t *d_winner, unsigned flags)
+{
+    if (!p || slot < 0 || slot >= p->depth) return fail(CRENDER_EINVAL, "crender_pipeline_bind: bad slot");
+    crender_pipeline::Bound &b = p->bound[slot];
+    b.tri = d_tri; b.col = d_col; b.nrm = d_nrm; b.T = T;
+    b.has_P = P16 != nullptr;
+    if (P16) std::memcpy(b.P, P16, sizeof b.P);
+    b.z = d_z; b.color = d_color; b.normal = d_normal; b.winner = d_winner; b.flags = flags;
+    b.set = true;
+    return CRENDER_OK;
+}
+
+int crender_pipeline_submit(crender_pipeline *p, void *stream)
+{
+    if (!p) return fail(CRENDER_EINVAL, "null pipeline");
+    const crender_pipeline::Bound &b = p->bound[p->n % (uint64_t)p->depth];
+    if (!b.set) return fail(CRENDER_EINVAL, "crender_pipeline_submit: slot not bound");
+    return crender_pipeline_frame(p, b.tri, b.col, b.nrm, b.T, b.has_P ? b.P : nullptr, b.z, b.color,
+                                  b.normal, b.winner, b.flags, stream);
 }
 
 int crender_pipeline_join(crender_pipeline *p, void *stream)

@@ -27,6 +27,7 @@ a vertex with z == 0 (out of contract; IEEE inf/NaN semantics apply instead).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -54,11 +55,20 @@ def _as_device_f32(a, name, device):
     return t
 
 
+def _current_raw_stream(device_index):
+    """Handle of torch's current stream on the device (the private fast path when this torch
+    has it: the public one builds a Stream object per call, ~1 us)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(device_index)
+    except AttributeError:
+        return torch.cuda.current_stream(device_index).cuda_stream
+
+
 class _FramePipeline:
     """Swap chain for ``render_frame`` (``crender_pipeline_*``): frame i renders on the library's
     stream i % depth with plan i % depth into framebuffer set i % depth, so up to `depth` frames
-    overlap on the GPU with no event between them (depth 3, triple buffering, measured best on
-    MI355X: T-Rex 1024^2 32.4 / 17.7 / 14.0 / 18.5 us per frame at depth 1 / 2 / 3 / 4).  Every frame still does all of its work
+    overlap on the GPU with no event between them (T-Rex 1024^2 on MI355X: 30 / 16 / 12.2 us per
+    frame at depth 1 / 2 / 3, 11.0 at depth 4 with GPU_MAX_HW_QUEUES=8).  Every frame still does all of its work
     (clear + project + bin + rasterize) into a complete framebuffer; the filler's
     ``z_buffer / color_buffer / normals_buffer`` always name the most recently submitted frame's
     set.  ``join`` orders the caller's stream after all submitted frames."""
@@ -92,7 +102,8 @@ class _FramePipeline:
         self.k = 0                 # set / stream / plan of the next frame (the library counts alike)
         self.n = 0
         self.pending = False
-        self._args = None
+        self._args = None          # (inputs, flags) the slots are bound to
+        self._submit = self.lib.crender_pipeline_submit
 
     def close(self):
         if self.handle:
@@ -103,26 +114,27 @@ class _FramePipeline:
         self.plans = []
 
     def frame(self, filler):
-        if self._args is None or self._args[0] is not filler._inputs:
+        if self._args is None or self._args[0] is not filler._inputs or self._args[1] != filler._extra_flags:
+            # everything but the stream is fixed while the resident model is: bind the arguments
+            # of every slot once, the per-frame call then passes two (ctypes spends ~0.3 us per
+            # argument; twelve per frame were a third of the host's time per frame)
             tri, col, nrm = filler._inputs
-            # everything but the stream is fixed while the resident model is: build the ctypes
-            # argument tuples (one per framebuffer set) once
-            per_set = []
-            for z, c, n, w in self.sets:
-                per_set.append((self.handle, tri.data_ptr(), col.data_ptr(), nrm.data_ptr(), tri.shape[0],
-                                filler._P, z.data_ptr(), c.data_ptr(), n.data_ptr(),
-                                None if w is None else w.data_ptr(),
-                                _capi.FUSED_CLEAR | filler._extra_flags))
-            self._args = (filler._inputs, per_set)
-        args = self._args[1][self.k]
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+            with torch.cuda.device(self.device):
+                for k, (z, c, n, w) in enumerate(self.sets):
+                    _capi.check(self.lib.crender_pipeline_bind(
+                        self.handle, k, tri.data_ptr(), col.data_ptr(), nrm.data_ptr(), tri.shape[0],
+                        filler._P, z.data_ptr(), c.data_ptr(), n.data_ptr(),
+                        None if w is None else w.data_ptr(), _capi.FUSED_CLEAR | filler._extra_flags),
+                        "crender_pipeline_bind")
+            self._args = (filler._inputs, filler._extra_flags)
+        stream = _current_raw_stream(self.device.index)
         if torch.cuda.current_device() == self.device.index:
-            rc = self.lib.crender_pipeline_frame(*args, stream)
+            rc = self._submit(self.handle, stream)
         else:                              # the library launches on the calling thread's device
             with torch.cuda.device(self.device):
-                rc = self.lib.crender_pipeline_frame(*args, stream)
+                rc = self._submit(self.handle, stream)
         if rc:
-            _capi.check(rc, "crender_pipeline_frame")
+            _capi.check(rc, "crender_pipeline_submit")
         # the filler's buffers are now this frame's
         filler.z_buffer, filler.color_buffer, filler.normals_buffer, filler.winner_buffer = self.sets[self.k]
         self.k = (self.k + 1) % self.depth
@@ -149,7 +161,7 @@ class _FramePipeline:
 class AdvancedPixelBufferFiller:
     def __init__(self, h, w, fov=90.0, z_near=0.1, z_far=1000.0, n_threads=1, *,
                  device=None, tile=0, row_strip=None, track_winner=False, cache_inputs=True,
-                 bin_capacity=0, direct_bins=True, pipeline=False, pipeline_depth=3):
+                 bin_capacity=0, direct_bins=True, pipeline=False, pipeline_depth=None):
         self._lib = _capi.load()                      # raises if the HIP library is missing
         if not torch.cuda.is_available():
             raise _capi.CrenderError("AdvancedPixelBufferFiller needs a ROCm GPU (no CPU fallback)")
@@ -187,6 +199,16 @@ class AdvancedPixelBufferFiller:
         self._host_fresh = False       # mirrors equal the device buffers
         self._host_exposed = False     # a mirror was handed out and may have been edited
         self._pipeline = bool(pipeline)  # render_frame(): overlap consecutive frames (see _FramePipeline)
+        if not pipeline_depth:
+            # measured on MI355X (scripts/ab_depth.sh): three frames in flight, or four for small
+            # frames when the HIP runtime may use more than its default of 4 hardware queues
+            # (GPU_MAX_HW_QUEUES >= 6, read by the runtime when it starts) — with 4 queues a
+            # fourth stream shares a queue with another one and the frames serialise
+            try:
+                queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+            except ValueError:
+                queues = 4
+            pipeline_depth = 4 if (self.h * self.w <= 1024 * 1024 and queues >= 6) else 3
         self._pipeline_depth = max(2, min(8, int(pipeline_depth)))
         self._pipe = None
 

@@ -168,6 +168,16 @@ CRENDER_API int crender_pipeline_frame(crender_pipeline *pipeline, const float *
                            float *d_z, float *d_color, float *d_normal, int32_t *d_winner,
                            unsigned flags, void *stream);
 CRENDER_API int crender_pipeline_join(crender_pipeline *pipeline, void *stream);
+/* The same with the per-frame arguments bound up front, for callers whose call overhead grows with
+ * the argument count (ctypes: ~4 us for crender_pipeline_frame's twelve): bind slot k = 0..depth-1
+ * (the arguments frame i with i % depth == k is to use; P16 is copied), then every
+ * crender_pipeline_submit renders the next frame of the rotation exactly as crender_pipeline_frame
+ * would with that slot's arguments.  Submitting an unbound slot is CRENDER_EINVAL. */
+CRENDER_API int crender_pipeline_bind(crender_pipeline *pipeline, int slot, const float *d_tri,
+                                      const float *d_col, const float *d_nrm, int64_t T,
+                                      const float *P16, float *d_z, float *d_color, float *d_normal,
+                                      int32_t *d_winner, unsigned flags);
+CRENDER_API int crender_pipeline_submit(crender_pipeline *pipeline, void *stream);
 
 /* Same contract as crender_raster, computed a second, independent way: one wavefront
  * per triangle, 64-bit global atomics on a packed (z, index) key plane, then a
