@@ -482,11 +482,11 @@ def test_c_abi_argument_errors(hip):
     from cython3dmodelrenderer_amd import _capi
     L = _capi.load()
     plan = C.c_void_p()
-    assert L.crender_plan_create(C.byref(plan), 64, 64, 10, 5, 10, 0, 0, None, 0, None) == _capi.EINVAL
+    assert L.crender_plan_create(C.byref(plan), 64, 64, 10, 5, 10, 0, 0, None, 0, None) == EINVAL
     assert b"geometry" in L.crender_last_error()
     assert L.crender_plan_workspace_bytes(0, 64, 0, 64, 10, 0, 0) == 0
-    assert L.crender_project(None, None, -1, None, 64, 64, None) == _capi.EINVAL
-    assert L.crender_clear(None, None, None, None, 64, 64, 0, 64, None) == _capi.EINVAL
+    assert L.crender_project(None, None, -1, None, 64, 64, None) == EINVAL
+    assert L.crender_clear(None, None, None, None, 64, 64, 0, 64, None) == EINVAL
     import torch
     ws = torch.empty(1024, dtype=torch.uint8, device="cuda:0")
     assert L.crender_plan_create(C.byref(plan), 64, 64, 0, 64, 1000, 0, 0, ws.data_ptr(), 1024,
@@ -649,6 +649,60 @@ def test_pipelined_frames_are_exact(oracle, depth):
             assert_bit_equal(filler.get_winner_tensor().cpu().numpy(), f.winner, "winner")
         filler.render_frame(pipelined=False)            # mixing plain frames in is fine too
         assert_bit_equal(filler.get_z_buffer(), f.z_buffer, "z after a plain frame")
+
+
+def test_pipeline_c_abi_frame_bind_submit(oracle, hip):
+    """crender_pipeline_* called directly: frames with explicit arguments and frames from bound
+    slots give the oracle's buffers in every framebuffer set; an unbound slot is refused."""
+    import ctypes as C
+    import torch
+    from cython3dmodelrenderer_amd import _capi
+    L, EINVAL = hip, 1          # CRENDER_EINVAL (include/crender_hip.h)
+    lib = _capi.load()
+    tri, col, nrm = scene("trex_inputs.npz")
+    H, W, depth = 200, 260, 3
+    f = oracle.OracleFiller(H, W, fov=45)
+    f.render_arrays(tri, col, nrm)
+    P = L.projection_matrix(45, 0.1, 1000.0, H, W)
+    d = [torch.from_numpy(a).cuda() for a in (tri, col, nrm)]
+    T = d[0].shape[0]
+    plans = [L.Plan(H, W, T) for _ in range(depth)]
+    fbs = [L.FrameBuffers(H, W, winner=True) for _ in range(depth)]
+    arr = (C.c_void_p * depth)(*[p.handle.value for p in plans])
+    pipe = C.c_void_p()
+    _capi.check(lib.crender_pipeline_create(C.byref(pipe), arr, depth), "create")
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        assert lib.crender_pipeline_submit(pipe, stream) == EINVAL       # nothing bound yet
+        for k, fb in enumerate(fbs):                                           # explicit arguments
+            _capi.check(lib.crender_pipeline_frame(
+                pipe, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), T, _capi.f32_16(P),
+                fb.z.data_ptr(), fb.color.data_ptr(), fb.normals.data_ptr(), fb.winner.data_ptr(),
+                _capi.FUSED_CLEAR, stream), "frame")
+        _capi.check(lib.crender_pipeline_join(pipe, stream), "join")
+        for fb in fbs:
+            z, c, n, w = fb.numpy()
+            assert_bit_equal(z, f.z_buffer, "z (frame)")
+            assert_bit_equal(w, f.winner, "winner (frame)")
+        assert lib.crender_pipeline_bind(pipe, depth, 0, 0, 0, 0, None, 0, 0, 0, 0, 0) == EINVAL
+        for k, fb in enumerate(fbs):                                           # bound slots
+            fb.z.fill_(-7.0)
+            _capi.check(lib.crender_pipeline_bind(
+                pipe, k, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), T, _capi.f32_16(P),
+                fb.z.data_ptr(), fb.color.data_ptr(), fb.normals.data_ptr(), fb.winner.data_ptr(),
+                _capi.FUSED_CLEAR), "bind")
+        for _ in range(2 * depth + 1):
+            _capi.check(lib.crender_pipeline_submit(pipe, stream), "submit")
+        _capi.check(lib.crender_pipeline_join(pipe, stream), "join")
+        for fb in fbs:
+            z, c, n, w = fb.numpy()
+            assert_bit_equal(z, f.z_buffer, "z (submit)")
+            assert_bit_equal(c, f.color_buffer, "colour (submit)")
+            assert_bit_equal(n, f.normals_buffer, "normal (submit)")
+            assert_bit_equal(w, f.winner, "winner (submit)")
+    finally:
+        torch.cuda.synchronize()
+        lib.crender_pipeline_destroy(pipe)
 
 
 def test_renderer_with_illumination(oracle):
