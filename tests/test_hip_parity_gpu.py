@@ -482,11 +482,11 @@ def test_c_abi_argument_errors(hip):
     from cython3dmodelrenderer_amd import _capi
     L = _capi.load()
     plan = C.c_void_p()
-    assert L.crender_plan_create(C.byref(plan), 64, 64, 10, 5, 10, 0, 0, None, 0, None) == EINVAL
+    assert L.crender_plan_create(C.byref(plan), 64, 64, 10, 5, 10, 0, 0, None, 0, None) == _capi.EINVAL
     assert b"geometry" in L.crender_last_error()
     assert L.crender_plan_workspace_bytes(0, 64, 0, 64, 10, 0, 0) == 0
-    assert L.crender_project(None, None, -1, None, 64, 64, None) == EINVAL
-    assert L.crender_clear(None, None, None, None, 64, 64, 0, 64, None) == EINVAL
+    assert L.crender_project(None, None, -1, None, 64, 64, None) == _capi.EINVAL
+    assert L.crender_clear(None, None, None, None, 64, 64, 0, 64, None) == _capi.EINVAL
     import torch
     ws = torch.empty(1024, dtype=torch.uint8, device="cuda:0")
     assert L.crender_plan_create(C.byref(plan), 64, 64, 0, 64, 1000, 0, 0, ws.data_ptr(), 1024,
@@ -657,7 +657,7 @@ def test_pipeline_c_abi_frame_bind_submit(oracle, hip):
     import ctypes as C
     import torch
     from cython3dmodelrenderer_amd import _capi
-    L, EINVAL = hip, 1          # CRENDER_EINVAL (include/crender_hip.h)
+    L = hip
     lib = _capi.load()
     tri, col, nrm = scene("trex_inputs.npz")
     H, W, depth = 200, 260, 3
@@ -673,7 +673,7 @@ def test_pipeline_c_abi_frame_bind_submit(oracle, hip):
     _capi.check(lib.crender_pipeline_create(C.byref(pipe), arr, depth), "create")
     stream = torch.cuda.current_stream().cuda_stream
     try:
-        assert lib.crender_pipeline_submit(pipe, stream) == EINVAL       # nothing bound yet
+        assert lib.crender_pipeline_submit(pipe, stream) == _capi.EINVAL       # nothing bound yet
         for k, fb in enumerate(fbs):                                           # explicit arguments
             _capi.check(lib.crender_pipeline_frame(
                 pipe, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), T, _capi.f32_16(P),
@@ -684,7 +684,7 @@ def test_pipeline_c_abi_frame_bind_submit(oracle, hip):
             z, c, n, w = fb.numpy()
             assert_bit_equal(z, f.z_buffer, "z (frame)")
             assert_bit_equal(w, f.winner, "winner (frame)")
-        assert lib.crender_pipeline_bind(pipe, depth, 0, 0, 0, 0, None, 0, 0, 0, 0, 0) == EINVAL
+        assert lib.crender_pipeline_bind(pipe, depth, 0, 0, 0, 0, None, 0, 0, 0, 0, 0) == _capi.EINVAL
         for k, fb in enumerate(fbs):                                           # bound slots
             fb.z.fill_(-7.0)
             _capi.check(lib.crender_pipeline_bind(
