@@ -19,11 +19,17 @@ HEADERS = ["raster_math.h", os.path.join("..", "..", "include", "crender_hip.h")
 #   -ffp-contract=off                           no FMA contraction (hipcc defaults to fast)
 #   -fhip-fp32-correctly-rounded-divide-sqrt    IEEE division / sqrt
 #   -fno-gpu-flush-denormals-to-zero            f32 denormals kept
+# Speed only:
+#   -fno-slp-vectorize   the SLP vectoriser pairs the barycentric arithmetic into v_pk_*_f32
+#                        ops, which cost as much as two scalar ops each plus ~20 register moves
+#                        per sample to line the operands up, and 10-25 more VGPRs; without it
+#                        every workload is 3-10 % faster (r01 A/B, same box)
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17",
     "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-fno-gpu-flush-denormals-to-zero",
+    "-fno-slp-vectorize",
     "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra",
 ]
 

@@ -71,11 +71,16 @@ int fail_hip(hipError_t e, const char *where)
     } while (0)
 
 constexpr int kThreads = 256;           // 4 wavefronts per workgroup
+// Waves per SIMD asked of k_raster (an upper bound on its VGPRs): the 16-pixel kernel needs 72
+// registers as it is (7 waves); the 32-pixel kernel is held to 80 (6 waves, 6 workgroups per
+// CU instead of 5: bunny 4096^2 +5 %, T-Rex 8192^2 raster 0.381 -> 0.341 ms; the fused-clear
+// instantiation fits without spilling, the compositing one spills 4 registers).  The 64-pixel
+// kernel is limited by its 48 KB of LDS, not by registers.  (r01 A/B, same box.)
 #ifndef CR_WPE16
-// Waves per SIMD asked of k_raster<16>: 6 caps it at 80 VGPRs (one spilled, 8 B of scratch)
-// instead of 92; with three frames in flight T-Rex 1024^2 gains 7 % (67.8k -> 72.7k fps), a
-// lone frame loses 1 % (r01 A/B, same box).  The 32/64-pixel kernels spill badly under a cap.
-#define CR_WPE16 6
+#define CR_WPE16 7
+#endif
+#ifndef CR_WPE32
+#define CR_WPE32 6
 #endif
 constexpr uint32_t kPixelPathRecords = 8;   // k_raster<16>: batches this short go pixel-parallel
 constexpr uint32_t kNoTiles = 0xFFFFFFFFu;
@@ -645,13 +650,8 @@ __device__ unsigned long long *g_stamps = nullptr;
 #define CR_STAMP(slot) do { } while (0)
 #endif
 
-// Register budget: the 32/64-pixel kernels declare no occupancy bound — capping them at 80
-// VGPRs (6 wavefronts per SIMD) was 3-5 % faster on the fill-heavy workloads, but its 32 B/lane
-// of scratch shows up as +5..+25 % WRITE_SIZE (r01 A/B, same box); they use 94-98 VGPRs, no
-// scratch.  The 16-pixel kernel has no large-record path and fits 80 with one spilled register
-// (CR_WPE16 above).
 template <int TS, bool CLEAR>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? CR_WPE16 : 1)))
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? CR_WPE16 : TS == 32 ? CR_WPE32 : 1)))
 void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
               const float *__restrict__ nrm, const uint32_t *__restrict__ offs,
               uint32_t *__restrict__ cursor, const uint32_t *__restrict__ entries, uint32_t capacity,
