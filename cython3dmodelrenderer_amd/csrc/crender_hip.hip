@@ -560,13 +560,36 @@ struct Work {
     T s;
     uint32_t id;
     int bx0, by0, bx1, by1;  // clipped pixel box [bx0, bx1) x [by0, by1)
-    int nbx, nblk;           // 4x4 blocks across, in total
+    int nbx, nblk;           // blocks across, in total
+    int lsx;                 // log2 of the block width (block = 2^lsx x 2^(4 - lsx) pixels)
 };
+
+// A block is 16 pixels: 4x4, or — 16-pixel tiles only, where most boxes are a few pixels wide or
+// high — 8x2 / 2x8 when that covers the box with fewer blocks (T-Rex 1024^2: 85.0 k -> 74.8 k
+// blocks per frame, the busiest tiles 400 -> 318).  The shape travels in bits 8..9 of box_wh
+// (box sides are <= 64): 0 = 4x4, 1 = 8x2, 2 = 2x8.
+CR_DEV int box_w(uint32_t wh) { return (int)(wh & 0xFF); }
+CR_DEV int box_h(uint32_t wh) { return (int)((wh >> 16) & 0xFF); }
+CR_DEV int shape_lsx(uint32_t wh) { const uint32_t s = (wh >> 8) & 3; return s == 1 ? 3 : s == 2 ? 1 : 2; }
+CR_DEV int blocks_shaped(int bw, int bh, int lsx)
+{
+    const int lsy = 4 - lsx;
+    return ((bw + (1 << lsx) - 1) >> lsx) * ((bh + (1 << lsy) - 1) >> lsy);
+}
+CR_DEV uint32_t pick_shape(uint32_t wh)   // wh without shape bits -> wh with them
+{
+    const int bw = box_w(wh), bh = box_h(wh);
+    const int c44 = blocks_shaped(bw, bh, 2), c82 = blocks_shaped(bw, bh, 3), c28 = blocks_shaped(bw, bh, 1);
+    uint32_t s = 0;
+    int best = c44;
+    if (c82 < best) { best = c82; s = 1; }
+    if (c28 < best) s = 2;
+    return wh | (s << 8);
+}
 
 CR_DEV int blocks_of(uint32_t box_wh)
 {
-    const int bw = box_wh & 0xFFFF, bh = box_wh >> 16;
-    return ((bw + 3) >> 2) * ((bh + 3) >> 2);
+    return blocks_shaped(box_w(box_wh), box_h(box_wh), shape_lsx(box_wh));
 }
 
 template <typename T>
@@ -577,11 +600,12 @@ CR_DEV Work<T> load_work(const WorkQueue &q, int r)
     const uint32_t xy = q.box_xy[r], wh = q.box_wh[r];
     w.bx0 = xy & 0xFFFF;
     w.by0 = xy >> 16;
-    const int bw = wh & 0xFFFF, bh = wh >> 16;
+    const int bw = box_w(wh), bh = box_h(wh);
     w.bx1 = w.bx0 + bw;
     w.by1 = w.by0 + bh;
-    w.nbx = (bw + 3) >> 2;
-    w.nblk = w.nbx * ((bh + 3) >> 2);
+    w.lsx = shape_lsx(wh);
+    w.nbx = (bw + (1 << w.lsx) - 1) >> w.lsx;
+    w.nblk = blocks_shaped(bw, bh, w.lsx);
     const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r], q.x2[r], q.y2[r], q.z2[r]};
     if constexpr (sizeof(T) == sizeof(TriXYZ)) w.s = t;
     else w.s = make_setup(t, w.nblk >= 16);
@@ -810,6 +834,7 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                 continue;   // (this was the list's last batch)
             }
         }
+        if constexpr (TS == 16) box_wh = pick_shape(box_wh);
         // wave-inclusive scan of the block counts
         const uint32_t my_blocks = (uint32_t)blocks_of(box_wh);
         uint32_t incl = my_blocks;
@@ -865,7 +890,9 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                     int b = (int)first;
                     int by = (int)(((float)b + 0.5f) * (1.0f / (float)wk.nbx)), bx = b - by * wk.nbx;
                     for (;;) {
-                        const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
+                        const int lsx = (TS == 16) ? wk.lsx : 2;   // 32/64-pixel tiles: always 4x4
+                        const int x = wk.bx0 + (bx << lsx) + (l & ((1 << lsx) - 1));
+                        const int y = wk.by0 + (by << (4 - lsx)) + (l >> lsx);
                         unsigned long long k;
                         if (x < wk.bx1 && y < wk.by1 && fragment(wk.s, wk.id, x, y, k))
                             lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
