@@ -92,6 +92,11 @@ struct Geom {
     int ntx, nty;  // tiles across / down the strip
     int ntiles;
     int tile_stride;  // odd-ish multiplier coprime to ntiles: scatters the dispatch order
+    // k_raster decodes its tile index once per workgroup; a runtime integer division costs ~30
+    // scalar instructions behind a v_rcp, three of them were 0.3 us at the head of every tile
+    // (and most of the kernel's SALU instructions).  Division by multiplication instead:
+    uint32_t ntx_magic;   // floor(2^32 / ntx) + 1: n / ntx == umulhi(n, magic) for n * ntx < 2^32; 0 = divide
+    double inv_ntiles;    // 1 / ntiles, for the 48-bit product of the scatter map
 };
 
 ProjConst make_proj(const float *P16, int w, int h)
@@ -690,10 +695,18 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
     // band of covered tiles is spread over the whole launch instead of arriving together
     // (T-Rex 8192^2: 0.446 -> 0.402 ms).  Small grids are faster in raster order
     // (T-Rex 1024^2: 24.7 vs 29.1 us), so the scatter starts at 32768 tiles.
-    if ((G.ntiles >= 32768) != ((dbg & 256) != 0))
-        tile = (int)(((unsigned long long)blockIdx.x * (unsigned)G.tile_stride) % (unsigned)G.ntiles);
-    int tx = tile % G.ntx;
-    const int ty = tile / G.ntx;
+    if ((G.ntiles >= 32768) != ((dbg & 256) != 0)) {
+        // (b * stride) mod ntiles, the product below 2^48: quotient from a double multiply
+        // (exact product, at most one off after rounding), remainder fixed up
+        const unsigned long long P = (unsigned long long)blockIdx.x * (unsigned)G.tile_stride;
+        const unsigned long long qd = (unsigned long long)((double)P * G.inv_ntiles);
+        long long r = (long long)(P - qd * (unsigned)G.ntiles);
+        if (r < 0) r += G.ntiles;
+        if (r >= G.ntiles) r -= G.ntiles;
+        tile = (int)r;
+    }
+    const int ty = G.ntx_magic ? (int)__umulhi((uint32_t)tile, G.ntx_magic) : tile / G.ntx;
+    int tx = tile - ty * G.ntx;
     // Workgroup b runs on XCD b % 8 and, there, on shader engine (b / 8) % 4, and the dispatcher
     // places workgroups strictly in order.  With a tile row that is a multiple of 32 tiles a
     // tile COLUMN would always meet the same (XCD, engine) pair: the pairs that own the columns
@@ -704,7 +717,8 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
     // after 3 us (T-Rex 1024^2 raster 24.0 -> 21.6 us, 73.3k -> 79.2k frames/s; the larger
     // frames gain 0-2 %).  CRENDER_DEBUG bit 512 turns it off.
     if (!(dbg & 512)) {
-        tx = (tx + 9 * ty) % G.ntx;
+        const int t = tx + 9 * ty;
+        tx = G.ntx_magic ? t - (int)__umulhi((uint32_t)t, G.ntx_magic) * G.ntx : t % G.ntx;
         tile = ty * G.ntx + tx;
     }
     const int X0 = tx * TS, Y0 = G.y0 + ty * TS;
@@ -1210,6 +1224,10 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
         int k = (int)(L.g.ntiles * 0.6180339887) | 1;
         while (k > 1 && gcd(k, L.g.ntiles) != 1) k += 2;
         L.g.tile_stride = k < 1 ? 1 : k;
+        // both dividends of k_raster's tile decode stay below ntiles + 9 * nty
+        const unsigned long long lim = ((unsigned long long)L.g.ntiles + 9ull * (unsigned)L.g.nty + L.g.ntx) * (unsigned)L.g.ntx;
+        L.g.ntx_magic = (lim < (1ull << 32) && L.g.ntx > 1) ? (uint32_t)((1ull << 32) / (unsigned)L.g.ntx) + 1u : 0u;
+        L.g.inv_ntiles = 1.0 / (double)L.g.ntiles;
     }
     L.max_T = max_T;
     if (cap <= 0) cap = 4 * max_T + 4 * (int64_t)L.g.ntiles + 65536;
