@@ -147,7 +147,7 @@ class _FramePipeline:
         self.k = 0                 # the library restarts its frame parity at a join
 
     def overflowed(self, filler):
-        """Synchronising check of both plans' bin lists."""
+        """Synchronising check of every plan's bin lists."""
         self.join(filler)
         for plan in self.plans:
             need, cap = C.c_int64(), C.c_int64()
@@ -363,9 +363,9 @@ class AdvancedPixelBufferFiller:
         """One benchmark frame: clear + project + rasterize the resident model
         (SURVEY.md section 8d 'one frame').  Inputs must have been set by a previous
         render_model / render_arrays call.  With ``pipeline=True`` (constructor) the filler is
-        a swap chain of two: consecutive frames render into alternating framebuffer sets on two
-        streams and overlap on the GPU; the buffer attributes and getters always refer to the
-        most recently submitted frame."""
+        a swap chain of ``pipeline_depth`` (3 or 4 by default): consecutive frames render into
+        rotating framebuffer sets on as many streams and overlap on the GPU; the buffer
+        attributes and getters always refer to the most recently submitted frame."""
         use_pipe = self._pipeline if pipelined is None else (pipelined and self._pipeline)
         if not use_pipe:
             self._launch(_capi.FUSED_CLEAR)      # (joins the pipeline first if frames are pending)
