@@ -364,29 +364,74 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
                 const int w = tx1 - tx0 + 1, cnt = w * (ty1 - ty0 + 1);
                 if (cnt <= kWideTiles) {
                     uint32_t slot[kWideTiles];
+                    int cx = 0, rowbase = ty0 * G.ntx + tx0;    // tile k of the range, stepped
 #pragma unroll
                     for (int k = 0; k < kWideTiles; ++k) {
-                        const int dy = k / (w > 0 ? w : 1);
-                        const int tile = (ty0 + dy) * G.ntx + tx0 + (k - dy * w);
-                        slot[k] = k < cnt ? atomicAdd(&count[tile], 1u) : 0u;
+                        slot[k] = k < cnt ? atomicAdd(&count[rowbase + cx], 1u) : 0u;
+                        if (++cx == w) { cx = 0; rowbase += G.ntx; }
                     }
+                    cx = 0; rowbase = ty0 * G.ntx + tx0;
 #pragma unroll
                     for (int k = 0; k < kWideTiles; ++k) {
                         if (k < cnt) {
-                            const int dy = k / w;
-                            const int tile = (ty0 + dy) * G.ntx + tx0 + (k - dy * w);
-                            if (slot[k] < dcap) dlist[(size_t)tile * dcap + slot[k]] = id;
+                            if (slot[k] < dcap) dlist[(size_t)(rowbase + cx) * dcap + slot[k]] = id;
                             else atomicMax(&hdr[1], slot[k] + 1);
                         }
+                        if (++cx == w) { cx = 0; rowbase += G.ntx; }
                     }
                     r_keep.x = kNoTiles;   // done; only wide ranges are left for the cooperative walk
                 }
             }
-            for_each_tile(r_keep, (uint32_t)(b0 + threadIdx.x), G.ntx, [&](int tile, uint32_t id) {
-                const uint32_t slot = atomicAdd(&count[tile], 1u);
-                if (slot < dcap) dlist[(size_t)tile * dcap + slot] = id;
-                else atomicMax(&hdr[1], slot + 1);
-            });
+            // Wide ranges: all of the wavefront's wide ranges are flattened into one run of
+            // (triangle, tile) pairs and walked 64 x 8 at a time, the round's atomics all in
+            // flight before its first store.  (One range after another, each paying its own
+            // memory round trip, a wavefront holding 20 large triangles took 40 us: that was the
+            // whole binning pass of bunny 4096^2.)
+            {
+                const int lane = threadIdx.x & 63;
+                int w = 0, cnt = 0, sx0 = 0, sy0 = 0;
+                if (r_keep.x != kNoTiles) {
+                    sx0 = r_keep.x & 0xFFFF; sy0 = r_keep.y & 0xFFFF;
+                    w = (int)(r_keep.x >> 16) - sx0 + 1;
+                    cnt = w * ((int)(r_keep.y >> 16) - sy0 + 1);      // <= kDirectMaxTilesPerTriangle
+                }
+                int incl = cnt;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int v = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += v;
+                }
+                const int total = __shfl(incl, 63, 64);
+                const uint32_t id0 = (uint32_t)b0 + (uint32_t)(threadIdx.x & ~63);
+                constexpr int kRound = 8;
+                for (int base = 0; base < total; base += 64 * kRound) {    // uniform: every lane takes
+                    const int j0 = base + lane;                             // every trip (shuffles inside)
+                    uint32_t slot[kRound], tile[kRound], who[kRound];
+#pragma unroll
+                    for (int u = 0; u < kRound; ++u) {
+                        const int j = j0 + 64 * u;
+                        int own = 0;     // first lane whose inclusive count exceeds j
+#pragma unroll
+                        for (int step = 32; step >= 1; step >>= 1)
+                            if (__shfl(incl, own + step - 1, 64) <= j) own += step;
+                        own &= 63;                                          // (j >= total: unused)
+                        const int ow = __shfl(w, own, 64), ocnt = __shfl(cnt, own, 64);
+                        const int ox0 = __shfl(sx0, own, 64), oy0 = __shfl(sy0, own, 64);
+                        const int i = j - (__shfl(incl, own, 64) - ocnt);   // tile number within the range
+                        const int dy = (int)(((float)i + 0.5f) * (1.0f / (float)(ow > 0 ? ow : 1)));  // exact: i < 2^22
+                        tile[u] = (uint32_t)((oy0 + dy) * G.ntx + ox0 + (i - dy * ow));
+                        who[u] = id0 + (uint32_t)own;
+                        slot[u] = j < total ? atomicAdd(&count[tile[u]], 1u) : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kRound; ++u) {
+                        if (j0 + 64 * u < total) {
+                            if (slot[u] < dcap) dlist[(size_t)tile[u] * dcap + slot[u]] = who[u];
+                            else atomicMax(&hdr[1], slot[u] + 1);
+                        }
+                    }
+                }
+            }
         } else {
             // list lengths: LDS histogram or global counters
             for_each_tile(r_keep, 0u, G.ntx, [&](int tile, uint32_t) {
