@@ -82,10 +82,12 @@ CRENDER_API int crender_clear(float *d_z, float *d_color, float *d_normal, int32
 /* ---- plan: frame geometry + carve-up of a caller-owned device workspace ----------
  * The tile rasterizer bins triangles into screen tiles; a plan fixes the strip, the
  * tile size and the capacity of the bin lists inside `d_workspace`.  The workspace
- * must stay allocated and untouched by others for the plan's lifetime. */
+ * must stay allocated and untouched by others for the plan's lifetime.  A plan (and a
+ * pipeline) belongs to the device that is current when it is created; calls using it must
+ * be made with that device current. */
 typedef struct crender_plan crender_plan;
 
-/* tile: 0 = automatic, 32 or 64.  bin_capacity: number of (tile, triangle) list
+/* tile: 0 = automatic (16 for frames up to 1024 x 1024, else 32), or 16, 32, 64.  bin_capacity: number of (tile, triangle) list
  * entries to reserve; 0 = automatic (4 per triangle + slack). */
 CRENDER_API size_t crender_plan_workspace_bytes(int H, int W, int y0, int y1, int64_t max_T,
                                     int64_t bin_capacity, int tile);
@@ -132,7 +134,7 @@ CRENDER_API int crender_render_model(crender_plan *plan, const float *d_tri, con
 
 /* crender_render_model in two halves, so that a caller can overlap the first half of the
  * next frame with the second half of the current one on another stream (two plans, double
- * buffering; cython3dmodelrenderer_amd's filler does this in `pipeline` mode):
+ * buffering; crender_pipeline_* below is the ready-made version with whole frames in flight):
  *   crender_prepare  K1 + binning into the plan.  P16 == NULL: d_tri is already projected.
  *   crender_draw     K2 from the plan's bins.  d_tri_proj == NULL: use the vertices
  *                    crender_prepare projected into the plan; T must equal the prepared T.
