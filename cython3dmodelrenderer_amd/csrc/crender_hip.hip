@@ -246,6 +246,19 @@ CR_DEV void for_each_tile(uint2 r, uint32_t payload, int ntx, F f)
 enum { kBinCountLds = 0, kBinCountGlobal = 1, kBinDirect = 2, kBinDirectGlobal = 3 };
 constexpr int kDirectMaxTilesPerTriangle = 1024;  // beyond this the scan path is used instead
 
+#ifdef CRENDER_STAMPS
+// Diagnostic build only: phase timestamps of k_setup's first batch, 8 per workgroup
+// (crender_debug_set_setup_stamps); same clock as k_raster's stamps.
+__device__ unsigned long long *g_setup_stamps = nullptr;
+#define CR_SETUP_STAMP(slot)                                                                 \
+    do {                                                                                     \
+        if (g_setup_stamps && threadIdx.x == 0 && b0 == c0)                                  \
+            g_setup_stamps[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64();                \
+    } while (0)
+#else
+#define CR_SETUP_STAMP(slot) do { } while (0)
+#endif
+
 // dynamic LDS: [hist: ntiles u32 if kBinCountLds][verts: 256*9 f32][normals: 256*9 f32]
 template <int TS, bool PROJECT, int BIN>
 __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tri_in,
@@ -277,12 +290,14 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
     __syncthreads();
     for (int64_t b0 = c0; b0 < c1; b0 += kThreads) {
         const int n = (int)((c1 - b0) < kThreads ? (c1 - b0) : kThreads);
+        CR_SETUP_STAMP(0);
         stage_in(tri_in + b0 * 9, sv, n * 9);
         stage_in(nrm + b0 * 9, sn, n * 9);
         if (BIN == kBinDirect && threadIdx.x == 0) {
             tile_box[0] = 0x7FFFFFFF; tile_box[1] = -1; tile_box[2] = 0x7FFFFFFF; tile_box[3] = -1;
         }
         __syncthreads();
+        CR_SETUP_STAMP(1);      // inputs staged
         uint2 r_keep = make_uint2(kNoTiles, 0);
         if ((int)threadIdx.x < n) {
             float *v = sv + threadIdx.x * 9;
@@ -332,11 +347,13 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
             const int tx_lo = tile_box[0], tx_hi = tile_box[1], ty_lo = tile_box[2], ty_hi = tile_box[3];
             const int bw = tx_hi - tx_lo + 1, area = tx_hi < 0 ? 0 : bw * (ty_hi - ty_lo + 1);
             auto box_tile = [&](int i) { const int dy = i / bw; return (ty_lo + dy) * G.ntx + tx_lo + (i - dy * bw); };
+            CR_SETUP_STAMP(2);  // projected, ranges known, tile box reduced
             for (int i = threadIdx.x; i < area; i += kThreads) hist[box_tile(i)] = 0;
             __syncthreads();
             // pass A: this batch's entries per tile
             for_each_tile(r_keep, 0u, G.ntx, [&](int tile, uint32_t) { atomicAdd(&hist[tile], 1u); });
             __syncthreads();
+            CR_SETUP_STAMP(3);  // pass A done
             if (PROJECT) stage_out(proj_out + b0 * 9, sv, n * 9);
             // pass B: one global atomic per touched tile reserves a run of that tile's list
             for (int i = threadIdx.x; i < area; i += kThreads) {
@@ -345,6 +362,7 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
                 if (c) hist[t] = atomicAdd(&count[t], c);
             }
             __syncthreads();
+            CR_SETUP_STAMP(4);  // pass B done (global atomics returned)
             // pass C: the batch's entries take consecutive slots of the run (LDS cursors)
             for_each_tile(r_keep, (uint32_t)(b0 + threadIdx.x), G.ntx, [&](int tile, uint32_t id) {
                 const uint32_t slot = atomicAdd(&hist[tile], 1u);
@@ -442,6 +460,7 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
             if (PROJECT) stage_out(proj_out + b0 * 9, sv, n * 9);
         }
         __syncthreads();
+        CR_SETUP_STAMP(5);      // batch done (stores issued)
     }
     if (BIN == kBinCountLds) {
         for (int i = threadIdx.x; i < G.ntiles; i += kThreads) {
@@ -1529,6 +1548,7 @@ int tile_frame(crender_plan *plan, bool project, const float *d_tri, const float
 extern "C" {
 #ifdef CRENDER_STAMPS
 CRENDER_API int crender_debug_set_stamps(void *d_buf);
+CRENDER_API int crender_debug_set_setup_stamps(void *d_buf);
 #endif
 
 int crender_abi_version(void) { return CRENDER_ABI_VERSION; }
@@ -1720,6 +1740,12 @@ int crender_render_model(crender_plan *plan, const float *d_tri, const float *d_
 }
 
 #ifdef CRENDER_STAMPS
+int crender_debug_set_setup_stamps(void *d_buf)
+{
+    unsigned long long *p = static_cast<unsigned long long *>(d_buf);
+    CR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_setup_stamps), &p, sizeof p));
+    return CRENDER_OK;
+}
 // diagnostic build: point the kernels at a stamp buffer (ntiles * 8 u64), or detach with null
 int crender_debug_set_stamps(void *d_buf)
 {

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Diagnostic: phase timestamps of k_setup's first batch per workgroup (-DCRENDER_STAMPS build)."""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from cython3dmodelrenderer_amd import _build
+dbg_lib = "/tmp/libcrender_hip_stamps.so"
+subprocess.check_call([_build._hipcc()] + _build.HIPCC_FLAGS + ["-DCRENDER_STAMPS", "-o", dbg_lib,
+                       os.path.join(_build.SRC_DIR, "crender_hip.hip")], stderr=subprocess.DEVNULL)
+_build.LIB_PATH = dbg_lib
+import torch
+from cython3dmodelrenderer_amd import _capi, scenes
+from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+wl = sys.argv[1] if len(sys.argv) > 1 else "trex1024"
+tri, col, nrm, (H, W), fov = scenes.scene(wl)
+L = _capi.load()
+f = AdvancedPixelBufferFiller(H, W, fov=fov)
+f.render_arrays(tri, col, nrm, clear=True); f.synchronize()
+nb = 4096
+buf = torch.zeros(nb * 8, dtype=torch.int64, device="cuda:0")
+L.crender_debug_set_setup_stamps.argtypes = [C.c_void_p]; L.crender_debug_set_setup_stamps.restype = C.c_int
+for _ in range(3): f.render_frame(pipelined=False)
+f.synchronize()
+assert L.crender_debug_set_setup_stamps(buf.data_ptr()) == 0
+f.render_frame(pipelined=False); f.synchronize()
+L.crender_debug_set_setup_stamps(None)
+s = buf.cpu().numpy().reshape(nb, 8).astype(np.int64) * 10      # ns
+s = s[s[:, 0] > 0]
+t0 = s[:, 0].min()
+names = ["start", "inputs staged", "ranges + tile box", "pass A (LDS counts)", "pass B (global atomics)", "batch done"]
+print(f"{wl}: {len(s)} workgroups; ns since the first workgroup's start (p50 / max)")
+for k, nm in enumerate(names):
+    v = s[:, k] - t0
+    if (s[:, k] > 0).all():
+        print(f"  {nm:28s} p50 {np.percentile(v, 50):7.0f}  max {v.max():7d}")
