@@ -77,7 +77,7 @@ constexpr int kThreads = 256;           // 4 wavefronts per workgroup
 // instantiation fits without spilling, the compositing one spills 4 registers).  The 64-pixel
 // kernel is limited by its 48 KB of LDS, not by registers.  (r01 A/B, same box.)
 #ifndef CR_WPE16
-#define CR_WPE16 7
+#define CR_WPE16 8
 #endif
 #ifndef CR_WPE32
 #define CR_WPE32 6
@@ -629,36 +629,15 @@ struct Work {
     T s;
     uint32_t id;
     int bx0, by0, bx1, by1;  // clipped pixel box [bx0, bx1) x [by0, by1)
-    int nbx, nblk;           // blocks across, in total
-    int lsx;                 // log2 of the block width (block = 2^lsx x 2^(4 - lsx) pixels)
+    int nbx, nblk;           // 4x4 blocks across, in total
 };
 
-// A block is 16 pixels: 4x4, or — 16-pixel tiles only, where most boxes are a few pixels wide or
-// high — 8x2 / 2x8 when that covers the box with fewer blocks (T-Rex 1024^2: 85.0 k -> 74.8 k
-// blocks per frame, the busiest tiles 400 -> 318).  The shape travels in bits 8..9 of box_wh
-// (box sides are <= 64): 0 = 4x4, 1 = 8x2, 2 = 2x8.
-CR_DEV int box_w(uint32_t wh) { return (int)(wh & 0xFF); }
-CR_DEV int box_h(uint32_t wh) { return (int)((wh >> 16) & 0xFF); }
-CR_DEV int shape_lsx(uint32_t wh) { const uint32_t s = (wh >> 8) & 3; return s == 1 ? 3 : s == 2 ? 1 : 2; }
-CR_DEV int blocks_shaped(int bw, int bh, int lsx)
-{
-    const int lsy = 4 - lsx;
-    return ((bw + (1 << lsx) - 1) >> lsx) * ((bh + (1 << lsy) - 1) >> lsy);
-}
-CR_DEV uint32_t pick_shape(uint32_t wh)   // wh without shape bits -> wh with them
-{
-    const int bw = box_w(wh), bh = box_h(wh);
-    const int c44 = blocks_shaped(bw, bh, 2), c82 = blocks_shaped(bw, bh, 3), c28 = blocks_shaped(bw, bh, 1);
-    uint32_t s = 0;
-    int best = c44;
-    if (c82 < best) { best = c82; s = 1; }
-    if (c28 < best) s = 2;
-    return wh | (s << 8);
-}
+CR_DEV int box_w(uint32_t wh) { return (int)(wh & 0xFFFF); }
+CR_DEV int box_h(uint32_t wh) { return (int)(wh >> 16); }
 
 CR_DEV int blocks_of(uint32_t box_wh)
 {
-    return blocks_shaped(box_w(box_wh), box_h(box_wh), shape_lsx(box_wh));
+    return ((box_w(box_wh) + 3) >> 2) * ((box_h(box_wh) + 3) >> 2);
 }
 
 template <typename T>
@@ -672,9 +651,8 @@ CR_DEV Work<T> load_work(const WorkQueue &q, int r)
     const int bw = box_w(wh), bh = box_h(wh);
     w.bx1 = w.bx0 + bw;
     w.by1 = w.by0 + bh;
-    w.lsx = shape_lsx(wh);
-    w.nbx = (bw + (1 << w.lsx) - 1) >> w.lsx;
-    w.nblk = blocks_shaped(bw, bh, w.lsx);
+    w.nbx = (bw + 3) >> 2;
+    w.nblk = w.nbx * ((bh + 3) >> 2);
     const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r], q.x2[r], q.y2[r], q.z2[r]};
     if constexpr (sizeof(T) == sizeof(TriXYZ)) w.s = t;
     else w.s = make_setup(t, w.nblk >= 16);
@@ -912,9 +890,12 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                 continue;   // (this was the list's last batch)
             }
         }
-        if constexpr (TS == 16) box_wh = pick_shape(box_wh);
-        // wave-inclusive scan of the block counts
-        const uint32_t my_blocks = (uint32_t)blocks_of(box_wh);
+        // 16-pixel tiles: the work is flattened per PIXEL of the clipped boxes, not per block
+        // (see the sweep below); elsewhere per 16-pixel block
+        constexpr bool per_pixel = TS == 16;
+        // wave-inclusive scan of the work counts
+        const uint32_t my_blocks = per_pixel ? (uint32_t)(box_w(box_wh) * box_h(box_wh))
+                                             : (uint32_t)blocks_of(box_wh);
         uint32_t incl = my_blocks;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -954,8 +935,26 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
             for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + q.wave_blocks[w];
             const int total = (int)wo[kThreads / 64];
             const int nrec = (int)((end - base) < (uint32_t)kThreads ? (end - base) : (uint32_t)kThreads);
-            // (a 16-pixel tile holds 16 blocks: its records are never large)
-            if (TS == 16 || (total < 16 * nrec && !(dbg & 8192)) || (dbg & 128)) {
+            if constexpr (per_pixel) {
+                // Every pixel of every clipped box is one work item; thread t takes items t,
+                // t + 256, ...  All lanes work on a sample that lies in its box (a 4x4 block
+                // of a small box is half empty: 71 % of T-Rex 1024^2's block lanes were inside
+                // their box, 40-50 % on its busiest tiles), and there is no per-group record
+                // walk.  The item's record comes from the same two-level search as a block's.
+                for (int e = tid; e < total; e += kThreads) {
+                    uint32_t i;
+                    const int r = find_record(q, wo, e, i);
+                    const uint32_t xy = q.box_xy[r];
+                    const int bw = box_w(q.box_wh[r]);
+                    // i / bw for i < 256, bw <= 16: the approximate reciprocal is exact enough
+                    const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bw));
+                    const int x = (int)(xy & 0xFFFF) + ((int)i - dy * bw), y = (int)(xy >> 16) + dy;
+                    const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
+                                   q.x2[r], q.y2[r], q.z2[r]};
+                    unsigned long long k;
+                    if (fragment(t, q.tri[r], x, y, k)) lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                }
+            } else if ((total < 16 * nrec && !(dbg & 8192)) || (dbg & 128)) {
                 // Small records: each of the 16 lane groups takes one contiguous run of blocks,
                 // so a record is set up by (almost) one group only; tight loop, plain division.
                 const int chunk = (total + 15) >> 4;
@@ -968,9 +967,7 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                     int b = (int)first;
                     int by = (int)(((float)b + 0.5f) * (1.0f / (float)wk.nbx)), bx = b - by * wk.nbx;
                     for (;;) {
-                        const int lsx = (TS == 16) ? wk.lsx : 2;   // 32/64-pixel tiles: always 4x4
-                        const int x = wk.bx0 + (bx << lsx) + (l & ((1 << lsx) - 1));
-                        const int y = wk.by0 + (by << (4 - lsx)) + (l >> lsx);
+                        const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
                         unsigned long long k;
                         if (x < wk.bx1 && y < wk.by1 && fragment(wk.s, wk.id, x, y, k))
                             lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
