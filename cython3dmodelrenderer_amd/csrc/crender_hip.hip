@@ -941,9 +941,24 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                 // of a small box is half empty: 71 % of T-Rex 1024^2's block lanes were inside
                 // their box, 40-50 % on its busiest tiles), and there is no per-group record
                 // walk.  The item's record comes from the same two-level search as a block's.
+                // (most batches fit the first wavefront's 64 slots: then the search needs no
+                // wavefront selection and only log2 of the record count steps)
+                const int first_n = nrec <= 1 ? 1 : (nrec > 64 ? 64 : 1 << (32 - __clz(nrec - 1)));
                 for (int e = tid; e < total; e += kThreads) {
                     uint32_t i;
-                    const int r = find_record(q, wo, e, i);
+                    int r;
+                    if (nrec <= 64) {
+                        int lo = 0;
+                        for (int n = first_n; n > 1;) {     // last slot with blk_scan <= e
+                            const int half = n >> 1;
+                            if (q.blk_scan[lo + half] <= (uint32_t)e) lo += half;
+                            n -= half;
+                        }
+                        r = lo;
+                        i = (uint32_t)e - q.blk_scan[lo];
+                    } else {
+                        r = find_record(q, wo, e, i);
+                    }
                     const uint32_t xy = q.box_xy[r];
                     const int bw = box_w(q.box_wh[r]);
                     // i / bw for i < 256, bw <= 16: the approximate reciprocal is exact enough
