@@ -608,8 +608,9 @@ CR_DEV void lds_key_min(unsigned long long *slot, unsigned long long k)
 }
 
 // One batch of (tile, triangle) work in LDS, struct-of-arrays, slot = thread index.
-// A record's pixel box (clipped to the tile) is cut into 4x4-pixel blocks, numbered
-// row-major; blk_scan holds the wave-local exclusive prefix of the block counts.
+// A record's pixel box (clipped to the tile) is cut into work items numbered row-major:
+// 4x4-pixel blocks on 32/64-pixel tiles, single pixels on 16-pixel tiles; blk_scan holds the
+// wave-local exclusive prefix of the item counts.
 struct WorkQueue {
     float x0[kThreads], y0[kThreads], z0[kThreads];
     float x1[kThreads], y1[kThreads], z1[kThreads];
@@ -617,7 +618,7 @@ struct WorkQueue {
     uint32_t tri[kThreads];
     uint32_t box_xy[kThreads];    // bx0 | by0 << 16  (frame pixel coordinates)
     uint32_t box_wh[kThreads];    // bw  | bh  << 16  (0 = no work)
-    uint32_t blk_scan[kThreads];  // exclusive prefix of block counts within the wavefront
+    uint32_t blk_scan[kThreads];  // exclusive prefix of item counts within the wavefront
     uint32_t wave_blocks[kThreads / 64];
     unsigned long long mask[kThreads];  // large-record batches: blocks that survive the cull
 };
@@ -926,7 +927,7 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
             cur_t = load_tri(proj + (size_t)cur_id * 9);
         }
 
-        // ---- sweep: the batch's blocks, flattened and split evenly ---------------------------
+        // ---- sweep: the batch's work items, flattened and split evenly -------------------------
         {
             const int l = tid & 15, lx = l & 3, ly = l >> 2;
             uint32_t wo[kThreads / 64 + 1];
