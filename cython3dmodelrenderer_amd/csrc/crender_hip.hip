@@ -23,7 +23,8 @@
 // needed for correct results and the kernels' default paths ignore them:
 //   1 no coverage work, 2 no shading (both produce WRONG images: ablation timing only),
 //   8 XCD-banded tile map, 16 never use direct bins, 32 no sign rejection, 64 no hoisted
-//   reciprocal, 128 small-record sweep for every batch, 256 invert the scatter-dispatch rule,
+//   reciprocal, 128 small-record block sweep for every batch (64-pixel tiles), 256 invert the
+//   scatter-dispatch rule,
 //   512 no row rotation of the tile map, 4096 coarse pass keeps every block, 8192 large-record
 //   sweep for every batch (32/64-pixel tiles), bits 16..23 = n + 1: pixel-parallel path of 16-pixel tiles for batches <= n records
 //   (n = 0 disables it; default kPixelPathRecords).
@@ -621,6 +622,9 @@ struct WorkQueue {
     uint32_t blk_scan[kThreads];  // exclusive prefix of item counts within the wavefront
     uint32_t wave_blocks[kThreads / 64];
     unsigned long long mask[kThreads];  // large-record batches: blocks that survive the cull
+    // 32-pixel tiles count a batch both ways (blocks above, pixels here) and pick the sweep after
+    uint32_t px_scan[kThreads];
+    uint32_t wave_px[kThreads / 64];
 };
 
 // The record a 16-lane group is sweeping.  T = TriXYZ (small records: the edge constants are
@@ -661,20 +665,22 @@ CR_DEV Work<T> load_work(const WorkQueue &q, int r)
 }
 
 // Flattened block index -> (wavefront, slot): the record holding block p of the batch.
-CR_DEV int find_record(const WorkQueue &q, const uint32_t *wo, int p, uint32_t &first_block)
+// (`scan` = the queue's wave-local exclusive prefix of the counts in question, `wo` the
+// exclusive prefix of the wavefronts' totals)
+CR_DEV int find_record(const uint32_t *scan, const uint32_t *wo, int p, uint32_t &first_block)
 {
     int w = 0;
 #pragma unroll
     for (int v = 1; v < kThreads / 64; ++v)
         if ((uint32_t)p >= wo[v]) w = v;
     const uint32_t pl = (uint32_t)p - wo[w];
-    int lo = w * 64, n = 64;   // last slot in [lo, lo + 64) with blk_scan <= pl
+    int lo = w * 64, n = 64;   // last slot in [lo, lo + 64) with scan <= pl
     while (n > 1) {
         const int half = n >> 1;
-        if (q.blk_scan[lo + half] <= pl) lo += half;
+        if (scan[lo + half] <= pl) lo += half;
         n -= half;
     }
-    first_block = pl - q.blk_scan[lo];
+    first_block = pl - scan[lo];
     return lo;
 }
 
@@ -685,7 +691,7 @@ CR_DEV void coarse_cull(WorkQueue &q, const uint32_t *wo, int total, int tid,
 {
     for (int p = tid; p < total; p += kThreads) {
         uint32_t first;
-        const int r = find_record(q, wo, p, first);
+        const int r = find_record(q.blk_scan, wo, p, first);
         const TriSetup s = make_setup(TriXYZ{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
                                              q.x2[r], q.y2[r], q.z2[r]}, false);
         const uint32_t xy = q.box_xy[r], wh = q.box_wh[r];
@@ -893,15 +899,20 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
         }
         // 16-pixel tiles: the work is flattened per PIXEL of the clipped boxes, not per block
         // (see the sweep below); elsewhere per 16-pixel block
-        constexpr bool per_pixel = TS == 16;
+        constexpr bool per_pixel = TS == 16;   // always the per-pixel sweep
+        constexpr bool either = TS == 32;      // counted both ways, the batch picks its sweep
         // wave-inclusive scan of the work counts
-        const uint32_t my_blocks = per_pixel ? (uint32_t)(box_w(box_wh) * box_h(box_wh))
-                                             : (uint32_t)blocks_of(box_wh);
-        uint32_t incl = my_blocks;
+        const uint32_t my_px = (uint32_t)(box_w(box_wh) * box_h(box_wh));
+        const uint32_t my_blocks = per_pixel ? my_px : (uint32_t)blocks_of(box_wh);
+        uint32_t incl = my_blocks, incl_px = my_px;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t v = __shfl_up(incl, d, 64);
             if (lane >= d) incl += v;
+            if constexpr (either) {
+                const uint32_t vp = __shfl_up(incl_px, d, 64);
+                if (lane >= d) incl_px += vp;
+            }
         }
         // previous batch's sweeps must be over before the queue is overwritten; this
         // barrier also orders the key initialisation before the first sweep
@@ -914,6 +925,10 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
         q.box_wh[tid] = box_wh;
         q.blk_scan[tid] = incl - my_blocks;
         if (lane == 63) q.wave_blocks[wave] = incl;
+        if constexpr (either) {
+            q.px_scan[tid] = incl_px - my_px;
+            if (lane == 63) q.wave_px[wave] = incl_px;
+        }
         __syncthreads();  // queue complete
 #ifdef CRENDER_STAMPS
         if (base == beg) CR_STAMP(6);
@@ -936,33 +951,33 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
             for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + q.wave_blocks[w];
             const int total = (int)wo[kThreads / 64];
             const int nrec = (int)((end - base) < (uint32_t)kThreads ? (end - base) : (uint32_t)kThreads);
-            if constexpr (per_pixel) {
-                // Every pixel of every clipped box is one work item; thread t takes items t,
-                // t + 256, ...  All lanes work on a sample that lies in its box (a 4x4 block
-                // of a small box is half empty: 71 % of T-Rex 1024^2's block lanes were inside
-                // their box, 40-50 % on its busiest tiles), and there is no per-group record
-                // walk.  The item's record comes from the same two-level search as a block's.
-                // (most batches fit the first wavefront's 64 slots: then the search needs no
-                // wavefront selection and only log2 of the record count steps)
+            // Per-pixel sweep: every pixel of every clipped box is one work item; thread t takes
+            // items t, t + 256, ...  All lanes work on a sample that lies in its box (a 4x4 block
+            // of a small box is mostly empty: 71 % of T-Rex 1024^2's block lanes were inside their
+            // box, 40-50 % on its busiest tiles, 35 % for the 10 M small triangles), and there is
+            // no per-group record walk.  The item's record comes from a two-level search of the
+            // prefix sums (most batches fit the first wavefront's 64 slots: then no wavefront
+            // selection and only log2 of the record count steps).
+            auto sweep_pixels = [&](const uint32_t *scan, const uint32_t *wo_, int total_) {
                 const int first_n = nrec <= 1 ? 1 : (nrec > 64 ? 64 : 1 << (32 - __clz(nrec - 1)));
-                for (int e = tid; e < total; e += kThreads) {
+                for (int e = tid; e < total_; e += kThreads) {
                     uint32_t i;
                     int r;
                     if (nrec <= 64) {
                         int lo = 0;
-                        for (int n = first_n; n > 1;) {     // last slot with blk_scan <= e
+                        for (int n = first_n; n > 1;) {     // last slot with scan <= e
                             const int half = n >> 1;
-                            if (q.blk_scan[lo + half] <= (uint32_t)e) lo += half;
+                            if (scan[lo + half] <= (uint32_t)e) lo += half;
                             n -= half;
                         }
                         r = lo;
-                        i = (uint32_t)e - q.blk_scan[lo];
+                        i = (uint32_t)e - scan[lo];
                     } else {
-                        r = find_record(q, wo, e, i);
+                        r = find_record(scan, wo_, e, i);
                     }
                     const uint32_t xy = q.box_xy[r];
                     const int bw = box_w(q.box_wh[r]);
-                    // i / bw for i < 256, bw <= 16: the approximate reciprocal is exact enough
+                    // i / bw for i < 1024, bw <= 32: the approximate reciprocal is exact enough
                     const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bw));
                     const int x = (int)(xy & 0xFFFF) + ((int)i - dy * bw), y = (int)(xy >> 16) + dy;
                     const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
@@ -970,7 +985,18 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                     unsigned long long k;
                     if (fragment(t, q.tri[r], x, y, k)) lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
                 }
-            } else if ((total < 16 * nrec && !(dbg & 8192)) || (dbg & 128)) {
+            };
+            bool small_by_pixel = false;    // 32-pixel tiles: small records go per pixel too
+            if constexpr (either) small_by_pixel = total < 16 * nrec && !(dbg & 8192);
+            if constexpr (per_pixel) {
+                sweep_pixels(q.blk_scan, wo, total);
+            } else if (small_by_pixel) {
+                uint32_t wop[kThreads / 64 + 1];
+                wop[0] = 0;
+#pragma unroll
+                for (int w = 0; w < kThreads / 64; ++w) wop[w + 1] = wop[w] + q.wave_px[w];
+                sweep_pixels(q.px_scan, wop, (int)wop[kThreads / 64]);
+            } else if (TS == 64 && ((total < 16 * nrec && !(dbg & 8192)) || (dbg & 128))) {
                 // Small records: each of the 16 lane groups takes one contiguous run of blocks,
                 // so a record is set up by (almost) one group only; tight loop, plain division.
                 const int chunk = (total + 15) >> 4;
@@ -978,7 +1004,7 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                 const int pend = (p + chunk < total) ? (p + chunk) : total;
                 if (p < pend) {
                     uint32_t first;
-                    int r = find_record(q, wo, p, first);
+                    int r = find_record(q.blk_scan, wo, p, first);
                     Work<TriXYZ> wk = load_work<TriXYZ>(q, r);
                     int b = (int)first;
                     int by = (int)(((float)b + 0.5f) * (1.0f / (float)wk.nbx)), bx = b - by * wk.nbx;
@@ -1037,7 +1063,7 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                     const int pend = (p + chunk < work) ? (p + chunk) : work;
                     if (p < pend) {
                         uint32_t first;
-                        int r = find_record(q, wo, p, first);
+                        int r = find_record(q.blk_scan, wo, p, first);
                         Work<TriSetup> wk = load_work<TriSetup>(q, r);
                         float inv_nbx = 1.0f / (float)wk.nbx;
                         // the record's survivor mask with everything before the current block cleared
@@ -1068,7 +1094,7 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                     const int pend = ((wave + 1) * wchunk < total) ? ((wave + 1) * wchunk) : total;
                     if (p < pend) {
                         uint32_t first;
-                        int r = find_record(q, wo, p, first);
+                        int r = find_record(q.blk_scan, wo, p, first);
                         Work<TriSetup> wk = load_work<TriSetup>(q, r);
                         int b = (int)first;
                         float inv_nbx = 1.0f / (float)wk.nbx;
