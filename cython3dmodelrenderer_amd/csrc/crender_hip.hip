@@ -24,10 +24,10 @@
 //   1 no coverage work, 2 no shading (both produce WRONG images: ablation timing only),
 //   8 XCD-banded tile map, 16 never use direct bins, 32 no sign rejection, 64 no hoisted
 //   reciprocal, 128 small-record block sweep for every batch (64-pixel tiles), 256 invert the
-//   scatter-dispatch rule,
-//   512 no row rotation of the tile map, 4096 coarse pass keeps every block, 8192 large-record
-//   sweep for every batch (32/64-pixel tiles), bits 16..23 = n + 1: pixel-parallel path of 16-pixel tiles for batches <= n records
-//   (n = 0 disables it; default kPixelPathRecords).
+//   scatter-dispatch rule, 512 no row rotation of the tile map, 4096 coarse pass keeps every
+//   block, 8192 large-record sweep for every batch (32/64-pixel tiles), bits 16..23 = n + 1:
+//   pixel-parallel path of 16-pixel tiles for batches <= n records (n = 0 disables it; default
+//   kPixelPathRecords).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
