@@ -55,13 +55,12 @@ def _as_device_f32(a, name, device):
     return t
 
 
-def _current_raw_stream(device_index):
-    """Handle of torch's current stream on the device (the private fast path when this torch
-    has it: the public one builds a Stream object per call, ~1 us)."""
-    try:
-        return torch._C._cuda_getCurrentRawStream(device_index)
-    except AttributeError:
-        return torch.cuda.current_stream(device_index).cuda_stream
+# Handle of torch's current stream on a device, and the current device index: the private fast
+# paths when this torch has them (the public ones build a Stream object / go through Python
+# wrappers per call, ~1 us of a 7 us frame on the host).
+_current_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream",
+                              lambda index: torch.cuda.current_stream(index).cuda_stream)
+_current_device = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)
 
 
 class _FramePipeline:
@@ -104,6 +103,7 @@ class _FramePipeline:
         self.pending = False
         self._args = None          # (inputs, flags) the slots are bound to
         self._submit = self.lib.crender_pipeline_submit
+        self._index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
     def close(self):
         if self.handle:
@@ -127,8 +127,8 @@ class _FramePipeline:
                         None if w is None else w.data_ptr(), _capi.FUSED_CLEAR | filler._extra_flags),
                         "crender_pipeline_bind")
             self._args = (filler._inputs, filler._extra_flags)
-        stream = _current_raw_stream(self.device.index)
-        if torch.cuda.current_device() == self.device.index:
+        stream = _current_raw_stream(self._index)
+        if _current_device() == self._index:
             rc = self._submit(self.handle, stream)
         else:                              # the library launches on the calling thread's device
             with torch.cuda.device(self.device):
@@ -370,13 +370,16 @@ class AdvancedPixelBufferFiller:
         if not use_pipe:
             self._launch(_capi.FUSED_CLEAR)      # (joins the pipeline first if frames are pending)
             return
-        T = self._inputs[0].shape[0]
-        if self._pipe is None or T > self._pipe.max_T:
-            if self._pipe is not None:
-                torch.cuda.synchronize(self.device)
-                self._pipe.close()
-            self._pipe = _FramePipeline(self, T, self._pipeline_depth)
-        self._pipe.frame(self)
+        pipe = self._pipe
+        if pipe is None or pipe._args is None or pipe._args[0] is not self._inputs:
+            # (first pipelined frame, or new inputs: the swap chain may have to grow)
+            T = self._inputs[0].shape[0]
+            if pipe is None or T > pipe.max_T:
+                if pipe is not None:
+                    torch.cuda.synchronize(self.device)
+                    pipe.close()
+                pipe = self._pipe = _FramePipeline(self, T, self._pipeline_depth)
+        pipe.frame(self)
         self._host_fresh = False
 
     def clear(self):
