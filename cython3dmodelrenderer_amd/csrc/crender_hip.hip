@@ -19,8 +19,9 @@
 // Build flags (see _build.py): -ffp-contract=off, correctly rounded division, denormals on —
 // float parity with the reference depends on them.
 //
-// CRENDER_DEBUG (environment, read once) is a bit mask of measurement knobs; none of them is
-// needed for correct results and the kernels' default paths ignore them:
+// Measurement knobs exist only in a development build (-DCRENDER_DEV_KNOBS, scripts/dev_build.sh):
+// there CRENDER_DEBUG (environment, read once) is a bit mask; the product library is compiled
+// without them (every `dbg & bit` below folds to 0):
 //   1 no coverage work, 2 no shading (both produce WRONG images: ablation timing only),
 //   8 XCD-banded tile map, 16 never use direct bins, 32 no sign rejection, 64 no hoisted
 //   reciprocal, 128 small-record block sweep for every batch (64-pixel tiles), 256 invert the
@@ -78,7 +79,7 @@ constexpr int kThreads = 256;           // 4 wavefronts per workgroup
 // instantiation fits without spilling, the compositing one spills 4 registers).  The 64-pixel
 // kernel is limited by its 48 KB of LDS, not by registers.  (r01 A/B, same box.)
 #ifndef CR_WPE16
-#define CR_WPE16 8
+#define CR_WPE16 7
 #endif
 #ifndef CR_WPE32
 #define CR_WPE32 6
@@ -113,6 +114,7 @@ ProjConst make_proj(const float *P16, int w, int h)
 // Triangle records are 36 B, so per-thread vector loads would be misaligned; a block
 // copies its contiguous chunk with unit-stride loads and each thread then reads its own
 // record at a 9-dword stride (odd => conflict-free across the 32 banks).
+template <int NT = kThreads>
 CR_DEV void stage_in(const float *__restrict__ g, float *__restrict__ s, int nfloats)
 {
     const bool aligned = (((uintptr_t)g) & 15u) == 0;
@@ -120,13 +122,14 @@ CR_DEV void stage_in(const float *__restrict__ g, float *__restrict__ s, int nfl
         const int n4 = nfloats >> 2;
         const float4 *g4 = reinterpret_cast<const float4 *>(g);
         float4 *s4 = reinterpret_cast<float4 *>(s);
-        for (int i = threadIdx.x; i < n4; i += kThreads) s4[i] = g4[i];
-        for (int i = (n4 << 2) + threadIdx.x; i < nfloats; i += kThreads) s[i] = g[i];
+        for (int i = threadIdx.x; i < n4; i += NT) s4[i] = g4[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < nfloats; i += NT) s[i] = g[i];
     } else {
-        for (int i = threadIdx.x; i < nfloats; i += kThreads) s[i] = g[i];
+        for (int i = threadIdx.x; i < nfloats; i += NT) s[i] = g[i];
     }
 }
 
+template <int NT = kThreads>
 CR_DEV void stage_out(float *__restrict__ g, const float *__restrict__ s, int nfloats)
 {
     const bool aligned = (((uintptr_t)g) & 15u) == 0;
@@ -134,10 +137,10 @@ CR_DEV void stage_out(float *__restrict__ g, const float *__restrict__ s, int nf
         const int n4 = nfloats >> 2;
         float4 *g4 = reinterpret_cast<float4 *>(g);
         const float4 *s4 = reinterpret_cast<const float4 *>(s);
-        for (int i = threadIdx.x; i < n4; i += kThreads) g4[i] = s4[i];
-        for (int i = (n4 << 2) + threadIdx.x; i < nfloats; i += kThreads) g[i] = s[i];
+        for (int i = threadIdx.x; i < n4; i += NT) g4[i] = s4[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < nfloats; i += NT) g[i] = s[i];
     } else {
-        for (int i = threadIdx.x; i < nfloats; i += kThreads) g[i] = s[i];
+        for (int i = threadIdx.x; i < nfloats; i += NT) g[i] = s[i];
     }
 }
 
@@ -186,28 +189,63 @@ __global__ __launch_bounds__(kThreads) void k_clear(float *__restrict__ zb, floa
 
 // ---- binning ----------------------------------------------------------------------
 // Tile range of a triangle packed as tx0 | tx1 << 16 (x) and ty0 | ty1 << 16 (y),
-// inclusive; kNoTiles in .x marks a culled / empty triangle.
+// inclusive; kNoTiles in .x marks a culled / empty triangle.  `bx`, `by` receive the pixel box
+// (xl | xr << 16, yt | yb << 16; rows clipped to the strip).
 template <int TS>
-CR_DEV uint2 tile_range(const TriXYZ &t, const Geom &G)
+CR_DEV uint2 tile_range(const TriXYZ &t, const Geom &G, uint32_t &bx, uint32_t &by)
 {
     int xl, xr, yt, yb;
     pixel_box(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2, G.W, G.H, xl, xr, yt, yb);
     // .pyx:209 skips an empty box; rows outside the strip never produce samples.
     if (yt < G.y0) yt = G.y0;
     if (yb > G.y1) yb = G.y1;
+    bx = (uint32_t)xl | ((uint32_t)xr << 16);
+    by = (uint32_t)yt | ((uint32_t)yb << 16);
     if (xl >= xr || yt >= yb) return make_uint2(kNoTiles, 0);
     const uint32_t tx0 = xl / TS, tx1 = (xr - 1) / TS;
     const uint32_t ty0 = (yt - G.y0) / TS, ty1 = (yb - 1 - G.y0) / TS;
     return make_uint2(tx0 | (tx1 << 16), ty0 | (ty1 << 16));
 }
+template <int TS>
+CR_DEV uint2 tile_range(const TriXYZ &t, const Geom &G)
+{
+    uint32_t bx, by;
+    return tile_range<TS>(t, G, bx, by);
+}
 
 // Visit every tile of each lane's tile range (r.x == kNoTiles: none).  Narrow ranges are
 // walked by their own lane; a range wider than kWideTiles is walked by the whole wavefront,
 // 64 tiles at a time, so one screen-filling triangle does not serialise a wavefront behind a
-// single lane.  Must be called by all 64 lanes.  f(tile, payload of the range's owner); the
-// owner's payload is fetched while every lane is still active (a shuffle from a lane that has
-// left a divergent loop would read nothing).
+// single lane.  Must be called by all 64 lanes.  f(tx, ty, lane that owns the range).
 constexpr int kWideTiles = 16;
+template <typename F>
+CR_DEV void for_each_tile_xy(uint2 r, F f)
+{
+    const int lane = threadIdx.x & 63;
+    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+    if (r.x != kNoTiles) {
+        tx0 = r.x & 0xFFFF; tx1 = r.x >> 16; ty0 = r.y & 0xFFFF; ty1 = r.y >> 16;
+    }
+    const int mine = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+    const bool wide = mine > kWideTiles;
+    if (!wide)
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) f(tx, ty, lane);
+    unsigned long long m = __ballot(wide);
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const uint32_t rx = __shfl(r.x, src, 64), ry = __shfl(r.y, src, 64);
+        const int sx0 = rx & 0xFFFF, sx1 = rx >> 16, sy0 = ry & 0xFFFF, sy1 = ry >> 16;
+        const int w = sx1 - sx0 + 1, n = w * (sy1 - sy0 + 1);
+        for (int i = lane; i < n; i += 64) {
+            const int dy = i / w;
+            f(sx0 + (i - dy * w), sy0 + dy, src);
+        }
+    }
+}
+// the same with a tile index and the owner's payload (a shuffle from a lane that has left a
+// divergent loop would read nothing, so the payload is fetched while every lane is active)
 template <typename F>
 CR_DEV void for_each_tile(uint2 r, uint32_t payload, int ntx, F f)
 {
@@ -236,24 +274,19 @@ CR_DEV void for_each_tile(uint2 r, uint32_t payload, int ntx, F f)
     }
 }
 
-// Binning mode of k_setup:
-//   kBinCountLds / kBinCountGlobal  count list lengths (LDS histogram or global atomics) and
-//                                   store each triangle's tile range for k_fill (scan path);
-//   kBinDirect                      small scenes: append the triangle index straight into
-//                                   fixed-capacity per-tile lists, no k_scan / k_fill.
-//   kBinDirectGlobal                the same on a large tile grid (few entries per tile, so
-//                                   the per-tile counters see little contention): one returning
-//                                   global atomic per entry, no LDS histogram.
-enum { kBinCountLds = 0, kBinCountGlobal = 1, kBinDirect = 2, kBinDirectGlobal = 3 };
-constexpr int kDirectMaxTilesPerTriangle = 1024;  // beyond this the scan path is used instead
+// Binning mode of k_setup (scan path: scenes of more than 65536 triangles, or direct bins
+// switched off): count list lengths in an LDS histogram or with global atomics and store each
+// triangle's tile range for k_fill.
+enum { kBinCountLds = 0, kBinCountGlobal = 1 };
+constexpr int kDirectMaxTilesPerTriangle = 4096;  // beyond this the scan path is used instead
 
 #ifdef CRENDER_STAMPS
-// Diagnostic build only: phase timestamps of k_setup's first batch, 8 per workgroup
+// Diagnostic build only: phase timestamps per workgroup of the setup kernels, 8 per workgroup
 // (crender_debug_set_setup_stamps); same clock as k_raster's stamps.
 __device__ unsigned long long *g_setup_stamps = nullptr;
 #define CR_SETUP_STAMP(slot)                                                                 \
     do {                                                                                     \
-        if (g_setup_stamps && threadIdx.x == 0 && b0 == c0)                                  \
+        if (g_setup_stamps && threadIdx.x == 0)                                              \
             g_setup_stamps[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64();                \
     } while (0)
 #else
@@ -266,24 +299,18 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
                                                     const float *__restrict__ nrm,
                                                     float *__restrict__ proj_out,
                                                     uint2 *__restrict__ trange,
-                                                    uint32_t *__restrict__ count,
-                                                    uint32_t *__restrict__ dlist, uint32_t dcap,
-                                                    uint32_t *__restrict__ hdr, int64_t T,
+                                                    uint32_t *__restrict__ count, int64_t T,
                                                     int64_t chunk, ProjConst P, Geom G)
 {
-    // the LDS histogram doubles as the block's list cursors in direct mode
-    constexpr bool LDS_HIST = BIN == kBinCountLds || BIN == kBinDirect;
+    constexpr bool LDS_HIST = BIN == kBinCountLds;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // count mode packs two 16-bit counters per word (a block's chunk is < 65536 triangles);
-    // direct mode needs 32-bit cursors
-    const int hist_words = BIN == kBinDirect ? ((G.ntiles + 3) & ~3)
-                         : BIN == kBinCountLds ? ((((G.ntiles + 1) >> 1) + 3) & ~3) : 0;
+    // two 16-bit counters per word (a block's chunk is < 65536 triangles)
+    const int hist_words = LDS_HIST ? ((((G.ntiles + 1) >> 1) + 3) & ~3) : 0;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem_raw);
     float *sv = reinterpret_cast<float *>(smem_raw) + hist_words;
     float *sn = sv + kThreads * 9;
 
-    __shared__ int tile_box[4];   // direct bins: tile bounding box of the batch (x0, x1, y0, y1)
-    if (BIN == kBinCountLds) {
+    if (LDS_HIST) {
         for (int i = threadIdx.x; i < hist_words; i += kThreads) hist[i] = 0;
     }
     const int64_t c0 = (int64_t)blockIdx.x * chunk;
@@ -291,14 +318,9 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
     __syncthreads();
     for (int64_t b0 = c0; b0 < c1; b0 += kThreads) {
         const int n = (int)((c1 - b0) < kThreads ? (c1 - b0) : kThreads);
-        CR_SETUP_STAMP(0);
         stage_in(tri_in + b0 * 9, sv, n * 9);
         stage_in(nrm + b0 * 9, sn, n * 9);
-        if (BIN == kBinDirect && threadIdx.x == 0) {
-            tile_box[0] = 0x7FFFFFFF; tile_box[1] = -1; tile_box[2] = 0x7FFFFFFF; tile_box[3] = -1;
-        }
         __syncthreads();
-        CR_SETUP_STAMP(1);      // inputs staged
         uint2 r_keep = make_uint2(kNoTiles, 0);
         if ((int)threadIdx.x < n) {
             float *v = sv + threadIdx.x * 9;
@@ -317,153 +339,19 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
                 const TriXYZ t{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]};
                 r = tile_range<TS>(t, G);
             }
-            if (BIN != kBinDirect && BIN != kBinDirectGlobal) trange[b0 + threadIdx.x] = r;
-            if ((BIN == kBinDirect || BIN == kBinDirectGlobal) && r.x != kNoTiles) {
-                const int ntl = (int)((r.x >> 16) - (r.x & 0xFFFF) + 1) * (int)((r.y >> 16) - (r.y & 0xFFFF) + 1);
-                if (ntl > kDirectMaxTilesPerTriangle) {
-                    atomicMax(&hdr[1], 0xFFFFFFFFu);  // sticky: this scene needs the scan path
-                    r.x = kNoTiles;
-                }
-            }
+            trange[b0 + threadIdx.x] = r;
             r_keep = r;
         }
-        if (BIN == kBinDirect) {
-            // A batch of consecutive triangles is a compact patch of the mesh: its lists touch
-            // a small rectangle of tiles.  Only that rectangle of the LDS histogram is zeroed,
-            // counted, reserved and reset, instead of all ntiles entries per pass.
-            int bx0 = 0x7FFFFFFF, bx1 = -1, by0 = 0x7FFFFFFF, by1 = -1;
-            if (r_keep.x != kNoTiles) {
-                bx0 = r_keep.x & 0xFFFF; bx1 = r_keep.x >> 16; by0 = r_keep.y & 0xFFFF; by1 = r_keep.y >> 16;
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                bx0 = min(bx0, __shfl_xor(bx0, d, 64)); bx1 = max(bx1, __shfl_xor(bx1, d, 64));
-                by0 = min(by0, __shfl_xor(by0, d, 64)); by1 = max(by1, __shfl_xor(by1, d, 64));
-            }
-            if ((threadIdx.x & 63) == 0 && bx1 >= 0) {
-                atomicMin(&tile_box[0], bx0); atomicMax(&tile_box[1], bx1);
-                atomicMin(&tile_box[2], by0); atomicMax(&tile_box[3], by1);
-            }
-            __syncthreads();
-            const int tx_lo = tile_box[0], tx_hi = tile_box[1], ty_lo = tile_box[2], ty_hi = tile_box[3];
-            const int bw = tx_hi - tx_lo + 1, area = tx_hi < 0 ? 0 : bw * (ty_hi - ty_lo + 1);
-            auto box_tile = [&](int i) { const int dy = i / bw; return (ty_lo + dy) * G.ntx + tx_lo + (i - dy * bw); };
-            CR_SETUP_STAMP(2);  // projected, ranges known, tile box reduced
-            for (int i = threadIdx.x; i < area; i += kThreads) hist[box_tile(i)] = 0;
-            __syncthreads();
-            // pass A: this batch's entries per tile
-            for_each_tile(r_keep, 0u, G.ntx, [&](int tile, uint32_t) { atomicAdd(&hist[tile], 1u); });
-            __syncthreads();
-            CR_SETUP_STAMP(3);  // pass A done
-            if (PROJECT) stage_out(proj_out + b0 * 9, sv, n * 9);
-            // pass B: one global atomic per touched tile reserves a run of that tile's list
-            for (int i = threadIdx.x; i < area; i += kThreads) {
-                const int t = box_tile(i);
-                const uint32_t c = hist[t];
-                if (c) hist[t] = atomicAdd(&count[t], c);
-            }
-            __syncthreads();
-            CR_SETUP_STAMP(4);  // pass B done (global atomics returned)
-            // pass C: the batch's entries take consecutive slots of the run (LDS cursors)
-            for_each_tile(r_keep, (uint32_t)(b0 + threadIdx.x), G.ntx, [&](int tile, uint32_t id) {
-                const uint32_t slot = atomicAdd(&hist[tile], 1u);
-                if (slot < dcap) dlist[(size_t)tile * dcap + slot] = id;
-                else atomicMax(&hdr[1], slot + 1);
-            });
-        } else if (BIN == kBinDirectGlobal) {
-            if (PROJECT) stage_out(proj_out + b0 * 9, sv, n * 9);
-            // A lane's returning atomics are independent of each other: issue them all, then
-            // store (a loop of "atomic, wait, store" would pay one memory round trip per tile).
-            {
-                const uint32_t id = (uint32_t)(b0 + threadIdx.x);
-                int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
-                if (r_keep.x != kNoTiles) {
-                    tx0 = r_keep.x & 0xFFFF; tx1 = r_keep.x >> 16; ty0 = r_keep.y & 0xFFFF; ty1 = r_keep.y >> 16;
-                }
-                const int w = tx1 - tx0 + 1, cnt = w * (ty1 - ty0 + 1);
-                if (cnt <= kWideTiles) {
-                    uint32_t slot[kWideTiles];
-                    int cx = 0, rowbase = ty0 * G.ntx + tx0;    // tile k of the range, stepped
-#pragma unroll
-                    for (int k = 0; k < kWideTiles; ++k) {
-                        slot[k] = k < cnt ? atomicAdd(&count[rowbase + cx], 1u) : 0u;
-                        if (++cx == w) { cx = 0; rowbase += G.ntx; }
-                    }
-                    cx = 0; rowbase = ty0 * G.ntx + tx0;
-#pragma unroll
-                    for (int k = 0; k < kWideTiles; ++k) {
-                        if (k < cnt) {
-                            if (slot[k] < dcap) dlist[(size_t)(rowbase + cx) * dcap + slot[k]] = id;
-                            else atomicMax(&hdr[1], slot[k] + 1);
-                        }
-                        if (++cx == w) { cx = 0; rowbase += G.ntx; }
-                    }
-                    r_keep.x = kNoTiles;   // done; only wide ranges are left for the cooperative walk
-                }
-            }
-            // Wide ranges: all of the wavefront's wide ranges are flattened into one run of
-            // (triangle, tile) pairs and walked 64 x 8 at a time, the round's atomics all in
-            // flight before its first store.  (One range after another, each paying its own
-            // memory round trip, a wavefront holding 20 large triangles took 40 us: that was the
-            // whole binning pass of bunny 4096^2.)
-            {
-                const int lane = threadIdx.x & 63;
-                int w = 0, cnt = 0, sx0 = 0, sy0 = 0;
-                if (r_keep.x != kNoTiles) {
-                    sx0 = r_keep.x & 0xFFFF; sy0 = r_keep.y & 0xFFFF;
-                    w = (int)(r_keep.x >> 16) - sx0 + 1;
-                    cnt = w * ((int)(r_keep.y >> 16) - sy0 + 1);      // <= kDirectMaxTilesPerTriangle
-                }
-                int incl = cnt;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int v = __shfl_up(incl, d, 64);
-                    if (lane >= d) incl += v;
-                }
-                const int total = __shfl(incl, 63, 64);
-                const uint32_t id0 = (uint32_t)b0 + (uint32_t)(threadIdx.x & ~63);
-                constexpr int kRound = 8;
-                for (int base = 0; base < total; base += 64 * kRound) {    // uniform: every lane takes
-                    const int j0 = base + lane;                             // every trip (shuffles inside)
-                    uint32_t slot[kRound], tile[kRound], who[kRound];
-#pragma unroll
-                    for (int u = 0; u < kRound; ++u) {
-                        const int j = j0 + 64 * u;
-                        int own = 0;     // first lane whose inclusive count exceeds j
-#pragma unroll
-                        for (int step = 32; step >= 1; step >>= 1)
-                            if (__shfl(incl, own + step - 1, 64) <= j) own += step;
-                        own &= 63;                                          // (j >= total: unused)
-                        const int ow = __shfl(w, own, 64), ocnt = __shfl(cnt, own, 64);
-                        const int ox0 = __shfl(sx0, own, 64), oy0 = __shfl(sy0, own, 64);
-                        const int i = j - (__shfl(incl, own, 64) - ocnt);   // tile number within the range
-                        const int dy = (int)(((float)i + 0.5f) * (1.0f / (float)(ow > 0 ? ow : 1)));  // exact: i < 2^22
-                        tile[u] = (uint32_t)((oy0 + dy) * G.ntx + ox0 + (i - dy * ow));
-                        who[u] = id0 + (uint32_t)own;
-                        slot[u] = j < total ? atomicAdd(&count[tile[u]], 1u) : 0u;
-                    }
-#pragma unroll
-                    for (int u = 0; u < kRound; ++u) {
-                        if (j0 + 64 * u < total) {
-                            if (slot[u] < dcap) dlist[(size_t)tile[u] * dcap + slot[u]] = who[u];
-                            else atomicMax(&hdr[1], slot[u] + 1);
-                        }
-                    }
-                }
-            }
-        } else {
-            // list lengths: LDS histogram or global counters
-            for_each_tile(r_keep, 0u, G.ntx, [&](int tile, uint32_t) {
-                if (LDS_HIST) atomicAdd(&hist[tile >> 1], (tile & 1) ? 0x10000u : 1u);
-                else atomicAdd(&count[tile], 1u);
-            });
-            __syncthreads();
-            if (PROJECT) stage_out(proj_out + b0 * 9, sv, n * 9);
-        }
+        // list lengths: LDS histogram or global counters
+        for_each_tile(r_keep, 0u, G.ntx, [&](int tile, uint32_t) {
+            if (LDS_HIST) atomicAdd(&hist[tile >> 1], (tile & 1) ? 0x10000u : 1u);
+            else atomicAdd(&count[tile], 1u);
+        });
         __syncthreads();
-        CR_SETUP_STAMP(5);      // batch done (stores issued)
+        if (PROJECT) stage_out(proj_out + b0 * 9, sv, n * 9);
+        __syncthreads();
     }
-    if (BIN == kBinCountLds) {
+    if (LDS_HIST) {
         for (int i = threadIdx.x; i < G.ntiles; i += kThreads) {
             const uint32_t c = (hist[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
             if (c) atomicAdd(&count[i], c);
@@ -471,8 +359,314 @@ __global__ __launch_bounds__(kThreads) void k_setup(const float *__restrict__ tr
     }
 }
 
+// ---- direct bins: one wavefront per 64 triangles ---------------------------------------------
+// Scenes of up to 65536 triangles skip the count / scan / fill passes: every tile owns a
+// fixed-capacity slab of 48-byte ENTRIES and the setup kernel appends to it directly, so the
+// frame is two launches.  An entry carries everything the raster kernel needs to sweep the
+// triangle — the nine projected coordinates, the triangle index and its pixel box — so that a
+// tile's workgroup gets its records with ONE dependent load after the list length instead of two
+// (index, then a gather of the vertices: 0.9 us of every covered tile's 6 us, in-kernel stamps).
+struct __attribute__((aligned(16))) BinEntry {
+    float v[9];      // x0 y0 z0 x1 y1 z1 x2 y2 z2 (projected)
+    uint32_t id;     // triangle index
+    uint32_t bx, by; // pixel box: xl | xr << 16, yt | yb << 16 (.pyx:132-175, rows clipped to the strip)
+};
+static_assert(sizeof(BinEntry) == 48, "three 16-byte pieces");
+constexpr int kEntryPieces = sizeof(BinEntry) / 16;
+
+// ---- heavy tiles (direct bins, 16-pixel tiles) ---------------------------------------------
+// A tile whose list reaches kHeavyAt entries is rasterized by four workgroups, one per 8x8
+// quadrant, instead of one: on T-Rex 1024^2 the 36 tiles with >= 64 records set the end of the
+// raster launch (in-kernel timeline, profiles/r02).  The append that crosses kHeavyAt registers
+// the tile: it draws an index from the frame's counter (hdr[2 + parity]) and, if one of the
+// launch's `hmax` helper triples is still free, raises the tile's flag and writes tile + 1 into
+// the triple's three slot words.  k_raster's helper workgroups take quadrants 1..3; the tile's
+// own workgroup takes quadrant 0 when the flag is up.  Flag and slots are reset by their
+// readers, the counter of the NEXT frame by k_raster.
+constexpr uint32_t kHeavyAt = 64;
+struct HeavyReg {
+    uint32_t *ctr = nullptr;     // this frame's counter; null = no splitting
+    uint32_t *flag = nullptr;    // [ntiles]
+    uint32_t *slots = nullptr;   // [3 * hmax]
+    uint32_t hmax = 0;
+    // dispatch-order hint (build_order): tiles the raster launch will clear in groups without
+    // looking at their lists.  The first entry that lands in such a tile declares the hint stale.
+    const unsigned char *grouped = nullptr;   // [ntiles], null = the launch is not ordered
+    uint32_t *hint_bad = nullptr;
+};
+
+CR_DEV void first_entry_of(const HeavyReg &hv, uint32_t tile)
+{
+    if (hv.grouped && hv.grouped[tile]) *hv.hint_bad = 1u;
+}
+
+CR_DEV void register_heavy(const HeavyReg &hv, uint32_t tile)
+{
+    const uint32_t idx = atomicAdd(hv.ctr, 1u);
+    if (idx < hv.hmax) {
+        hv.flag[tile] = 1u;
+        hv.slots[3 * idx] = tile + 1; hv.slots[3 * idx + 1] = tile + 1; hv.slots[3 * idx + 2] = tile + 1;
+    }
+}
+
+// The 64 entries of the wavefront as staged in LDS (NP 16-byte pieces each): any lane can write
+// any owner's entry.
+template <int NP>
+CR_DEV void put_entry(float4 *__restrict__ dst, const float4 *img, int owner)
+{
+    const float4 *src = img + owner * NP;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) dst[k] = src[k];
+}
+
+// Append with one returning global atomic per (triangle, tile) pair — the fallback for a
+// wavefront whose triangles span more tiles than its LDS histogram holds (large triangles).
+template <int NP>
+CR_DEV void bin_direct_append(uint2 r_keep, const float4 *img, int ntx,
+                              uint32_t *__restrict__ count, float4 *__restrict__ bins,
+                              uint32_t dcap, uint32_t *__restrict__ hdr, const HeavyReg hv)
+{
+    const int lane = threadIdx.x & 63;
+    // A lane's returning atomics are independent of each other: issue them all, then
+    // store (a loop of "atomic, wait, store" would pay one memory round trip per tile).
+    {
+        int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+        if (r_keep.x != kNoTiles) {
+            tx0 = r_keep.x & 0xFFFF; tx1 = r_keep.x >> 16; ty0 = r_keep.y & 0xFFFF; ty1 = r_keep.y >> 16;
+        }
+        const int wd = tx1 - tx0 + 1, cnt = wd * (ty1 - ty0 + 1);
+        if (cnt <= kWideTiles) {
+            uint32_t slot[kWideTiles];
+            int cx = 0, rowbase = ty0 * ntx + tx0;    // tile k of the range, stepped
+#pragma unroll
+            for (int k = 0; k < kWideTiles; ++k) {
+                slot[k] = k < cnt ? atomicAdd(&count[rowbase + cx], 1u) : 0u;
+                if (++cx == wd) { cx = 0; rowbase += ntx; }
+            }
+            cx = 0; rowbase = ty0 * ntx + tx0;
+#pragma unroll
+            for (int k = 0; k < kWideTiles; ++k) {
+                if (k < cnt) {
+                    if (slot[k] < dcap) put_entry<NP>(bins + ((size_t)(rowbase + cx) * dcap + slot[k]) * NP, img, lane);
+                    else atomicMax(&hdr[1], slot[k] + 1);
+                    if (hv.ctr && slot[k] == kHeavyAt - 1) register_heavy(hv, (uint32_t)(rowbase + cx));
+                    if (slot[k] == 0) first_entry_of(hv, (uint32_t)(rowbase + cx));
+                }
+                if (++cx == wd) { cx = 0; rowbase += ntx; }
+            }
+            r_keep.x = kNoTiles;   // done; only wide ranges are left for the cooperative walk
+        }
+    }
+    // Wide ranges: all of the wavefront's wide ranges are flattened into one run of
+    // (triangle, tile) pairs and walked 64 x 8 at a time, the round's atomics all in
+    // flight before its first store.  (One range after another, each paying its own
+    // memory round trip, a wavefront holding 20 large triangles took 40 us: that was the
+    // whole binning pass of bunny 4096^2.)
+    if (__ballot(r_keep.x != kNoTiles) == 0) return;
+    {
+        int wd = 0, cnt = 0, sx0 = 0, sy0 = 0;
+        if (r_keep.x != kNoTiles) {
+            sx0 = r_keep.x & 0xFFFF; sy0 = r_keep.y & 0xFFFF;
+            wd = (int)(r_keep.x >> 16) - sx0 + 1;
+            cnt = wd * ((int)(r_keep.y >> 16) - sy0 + 1);      // <= kDirectMaxTilesPerTriangle
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        const int total = __shfl(incl, 63, 64);
+        constexpr int kRound = 8;
+        for (int base = 0; base < total; base += 64 * kRound) {    // uniform: every lane takes
+            const int j0 = base + lane;                             // every trip (shuffles inside)
+            uint32_t slot[kRound], tile[kRound];
+            int who[kRound];
+#pragma unroll
+            for (int u = 0; u < kRound; ++u) {
+                const int j = j0 + 64 * u;
+                int own = 0;     // first lane whose inclusive count exceeds j
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1)
+                    if (__shfl(incl, own + step - 1, 64) <= j) own += step;
+                own &= 63;                                          // (j >= total: unused)
+                const int ow = __shfl(wd, own, 64), ocnt = __shfl(cnt, own, 64);
+                const int ox0 = __shfl(sx0, own, 64), oy0 = __shfl(sy0, own, 64);
+                const int i = j - (__shfl(incl, own, 64) - ocnt);   // tile number within the range
+                const int dy = (int)(((float)i + 0.5f) * (1.0f / (float)(ow > 0 ? ow : 1)));  // exact: i < 2^22
+                tile[u] = (uint32_t)((oy0 + dy) * ntx + ox0 + (i - dy * ow));
+                who[u] = own;
+                slot[u] = j < total ? atomicAdd(&count[tile[u]], 1u) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kRound; ++u) {
+                if (j0 + 64 * u < total) {
+                    if (slot[u] < dcap) put_entry<NP>(bins + ((size_t)tile[u] * dcap + slot[u]) * NP, img, who[u]);
+                    else atomicMax(&hdr[1], slot[u] + 1);
+                    if (hv.ctr && slot[u] == kHeavyAt - 1) register_heavy(hv, tile[u]);
+                    if (slot[u] == 0) first_entry_of(hv, tile[u]);
+                }
+            }
+        }
+    }
+}
+
+// The 256-thread k_setup above walks a chain of barriers with ceil(T / 256) workgroups: 54 for
+// T-Rex, a fifth of the chip's CUs, 11 us per launch of which 2 us were the staging of its inputs
+// alone (in-kernel stamps, profiles/r02).  Direct bins need no block-level cooperation, so here a
+// workgroup IS one wavefront (its barrier is free): 64 triangles staged through LDS with
+// unit-stride float4 loads, projected, culled and boxed; ceil(T / 64) workgroups spread over the
+// CUs.  The appends are aggregated per wavefront — consecutive triangles of a mesh land in the
+// same few tiles, and one returning global atomic per (triangle, tile) pair serialises on the
+// counters of the busy tiles (250 entries on one counter: 2.8 us at the 11 ns one address takes):
+//   A  count the wavefront's entries per tile in an LDS histogram over its tile bounding box,
+//   B  one returning global atomic per touched tile reserves a run of that tile's slab,
+//   C  the entries take consecutive slots of the run (LDS cursors) and are written out.
+// A wavefront whose box exceeds the histogram (large triangles) appends pair by pair.
+constexpr int kWave = 64;
+constexpr int kWaveHistTiles = 512;       // 8 rounds of 64 lanes in pass B
+template <int TS, bool PROJECT>
+__global__ __launch_bounds__(kWave) void k_setup_wave(const float *__restrict__ tri_in,
+                                                      const float *__restrict__ nrm,
+                                                      float *__restrict__ proj_out,
+                                                      uint32_t *__restrict__ count,
+                                                      float4 *__restrict__ bins, uint32_t dcap,
+                                                      uint32_t *__restrict__ hdr, HeavyReg hv, int64_t T,
+                                                      ProjConst P, Geom G)
+{
+    constexpr int NP = kEntryPieces;                         // 16-byte pieces per entry
+    __shared__ __attribute__((aligned(16))) float sv[kWave * 9];
+    __shared__ __attribute__((aligned(16))) float4 img[kWave * NP];   // the wavefront's entries
+    __shared__ uint32_t hist[kWaveHistTiles];
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    const int n = (int)((T - b0) < kWave ? (T - b0) : kWave);
+    CR_SETUP_STAMP(0);
+    stage_in<kWave>(tri_in + b0 * 9, sv, n * 9);
+    // only the normals' z components are needed (.pyx:202): three strided loads per lane
+    float nz0 = 0.0f, nz1 = 0.0f, nz2 = 0.0f;
+    if (lane < n) {
+        const float *nn = nrm + (b0 + lane) * 9;
+        nz0 = nn[2]; nz1 = nn[5]; nz2 = nn[8];
+    }
+    __syncthreads();
+    CR_SETUP_STAMP(1);      // inputs staged
+    uint2 r = make_uint2(kNoTiles, 0);
+    if (lane < n) {
+        float *v = sv + lane * 9;
+        float a[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a[i] = v[i];
+        if (PROJECT) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) project_vertex(P, a + 3 * c);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) v[i] = a[i];
+        }
+        uint32_t bx = 0, by = 0;
+        const TriXYZ t{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]};
+        if (!backface(nz0, nz1, nz2)) r = tile_range<TS>(t, G, bx, by);
+        if (r.x != kNoTiles) {
+            const int ntl = (int)((r.x >> 16) - (r.x & 0xFFFF) + 1) * (int)((r.y >> 16) - (r.y & 0xFFFF) + 1);
+            if (ntl > kDirectMaxTilesPerTriangle) {
+                atomicMax(&hdr[1], 0xFFFFFFFFu);  // sticky: this scene needs the scan path
+                r.x = kNoTiles;
+            }
+        }
+        // this triangle's entry, as every tile of its range will get it
+        float4 *e = img + lane * NP;
+        e[0] = make_float4(a[0], a[1], a[2], a[3]);
+        e[1] = make_float4(a[4], a[5], a[6], a[7]);
+        e[2] = make_float4(a[8], __uint_as_float((uint32_t)(b0 + lane)), __uint_as_float(bx), __uint_as_float(by));
+    }
+    // tile bounding box of the wavefront's ranges
+    int X0 = 0x7FFFFFFF, X1 = -1, Y0 = 0x7FFFFFFF, Y1 = -1;
+    if (r.x != kNoTiles) {
+        X0 = r.x & 0xFFFF; X1 = r.x >> 16; Y0 = r.y & 0xFFFF; Y1 = r.y >> 16;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        X0 = min(X0, __shfl_xor(X0, d, 64)); X1 = max(X1, __shfl_xor(X1, d, 64));
+        Y0 = min(Y0, __shfl_xor(Y0, d, 64)); Y1 = max(Y1, __shfl_xor(Y1, d, 64));
+    }
+    __syncthreads();        // projected vertices and entries visible to every lane
+    CR_SETUP_STAMP(2);      // projected, ranges known
+    if (PROJECT) stage_out<kWave>(proj_out + b0 * 9, sv, n * 9);
+    if (X1 < 0) return;     // nothing to bin (uniform)
+    const int bw = X1 - X0 + 1, area = bw * (Y1 - Y0 + 1);
+    if (area > kWaveHistTiles) {
+        bin_direct_append<NP>(r, img, G.ntx, count, bins, dcap, hdr, hv);
+        return;
+    }
+    for (int i = lane; i < area; i += kWave) hist[i] = 0;
+    __syncthreads();
+    for_each_tile_xy(r, [&](int tx, int ty, int) { atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u); });
+    __syncthreads();
+    CR_SETUP_STAMP(3);      // pass A done
+    {
+        constexpr int kRounds = kWaveHistTiles / kWave;
+        const float rbw = 1.0f / (float)bw;
+        uint32_t c[kRounds], t[kRounds], base[kRounds];
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            const int i = k * kWave + lane;
+            c[k] = (k * kWave < area && i < area) ? hist[i] : 0u;
+            const int dy = (int)(((float)i + 0.5f) * rbw);          // exact: i < 2^22
+            t[k] = (uint32_t)((Y0 + dy) * G.ntx + X0 + (i - dy * bw));
+        }
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k)
+            base[k] = c[k] ? atomicAdd(&count[t[k]], c[k]) : 0u;     // all issued before any is used
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            if (c[k]) {
+                hist[k * kWave + lane] = base[k];
+                if (base[k] + c[k] > dcap) atomicMax(&hdr[1], base[k] + c[k]);
+                if (hv.ctr && base[k] < kHeavyAt && base[k] + c[k] >= kHeavyAt) register_heavy(hv, t[k]);
+                if (base[k] == 0) first_entry_of(hv, t[k]);
+            }
+        }
+    }
+    __syncthreads();
+    CR_SETUP_STAMP(4);      // pass B done (global atomics returned)
+    // a lane's own (narrow) range: every LDS cursor first, then the entries
+    {
+        int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+        if (r.x != kNoTiles) {
+            tx0 = r.x & 0xFFFF; tx1 = r.x >> 16; ty0 = r.y & 0xFFFF; ty1 = r.y >> 16;
+        }
+        const int wd = tx1 - tx0 + 1, cnt = wd * (ty1 - ty0 + 1);
+        if (cnt <= kWideTiles) {
+            uint32_t slot[kWideTiles];
+            int cx = 0, hrow = (ty0 - Y0) * bw + (tx0 - X0);
+#pragma unroll
+            for (int k = 0; k < kWideTiles; ++k) {
+                slot[k] = k < cnt ? atomicAdd(&hist[hrow + cx], 1u) : 0u;
+                if (++cx == wd) { cx = 0; hrow += bw; }
+            }
+            cx = 0;
+            int trow = ty0 * G.ntx + tx0;
+#pragma unroll
+            for (int k = 0; k < kWideTiles; ++k) {
+                if (k < cnt && slot[k] < dcap)
+                    put_entry<NP>(bins + ((size_t)(trow + cx) * dcap + slot[k]) * NP, img, lane);
+                if (++cx == wd) { cx = 0; trow += G.ntx; }
+            }
+            r.x = kNoTiles;   // done; only wide ranges are left for the cooperative walk
+        }
+    }
+    for_each_tile_xy(r, [&](int tx, int ty, int owner) {
+        const uint32_t slot = atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u);
+        if (slot < dcap) put_entry<NP>(bins + ((size_t)(ty * G.ntx + tx) * dcap + slot) * NP, img, owner);
+    });
+    CR_SETUP_STAMP(5);      // entries issued
+}
+
 // Exclusive scan of count[0..ntiles) into offs[0..ntiles]; count is zeroed (k_fill uses
-// it as the per-tile cursor); hdr[0] = total number of list entries this frame needs.
+// it as the per-tile cursor); hdr[0] / hdr[4] = low / high word of the number of list entries
+// this frame needs.  The running sum is kept in 64 bits and the offsets saturate at 2^32 - 1, so
+// a frame that needs more entries than 32 bits can index reports an unsatisfiable figure instead
+// of a wrapped one (k_raster clamps every range to the capacity: such tiles come out empty).
 // One 1024-thread workgroup walks the array in coalesced slabs of 4096 counters (4
 // consecutive ones per thread), the next slab's loads in flight while the current one is
 // scanned with wavefront shuffles + one LDS exchange of the 16 wavefront totals.
@@ -480,41 +674,42 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t *__restrict__ count,
                                                uint32_t *__restrict__ offs,
                                                uint32_t *__restrict__ hdr, int ntiles)
 {
-    __shared__ uint32_t wave_total[2][16];
+    __shared__ unsigned long long wave_total[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto load4 = [&](int base, uint32_t c[4]) {
         const int i = base + tid * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[k] = (i + k < ntiles) ? count[i + k] : 0u;
     };
+    auto sat = [](unsigned long long v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; };
     uint32_t cur[4], nxt[4];
     load4(0, cur);
-    uint32_t carry = 0;
+    unsigned long long carry = 0;
     int buf = 0;
     for (int base = 0; base < ntiles; base += 4096, buf ^= 1) {
         if (base + 4096 < ntiles) load4(base + 4096, nxt);
-        const uint32_t s = cur[0] + cur[1] + cur[2] + cur[3];
-        uint32_t incl = s;
+        const unsigned long long s = (unsigned long long)cur[0] + cur[1] + cur[2] + cur[3];
+        unsigned long long incl = s;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t v = __shfl_up(incl, d, 64);
+            const unsigned long long v = __shfl_up(incl, d, 64);
             if (lane >= d) incl += v;
         }
         if (lane == 63) wave_total[buf][wave] = incl;
         __syncthreads();   // (the other buffer is free: its readers passed the previous barrier)
-        uint32_t before = 0, total = 0;
+        unsigned long long before = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) {
-            const uint32_t t = wave_total[buf][w];
+            const unsigned long long t = wave_total[buf][w];
             if (w < wave) before += t;
             total += t;
         }
-        uint32_t run = carry + before + incl - s;
+        unsigned long long run = carry + before + incl - s;
         const int i = base + tid * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (i + k < ntiles) {
-                offs[i + k] = run;
+                offs[i + k] = sat(run);
                 count[i + k] = 0;
             }
             run += cur[k];
@@ -524,8 +719,9 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t *__restrict__ count,
         for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
     }
     if (tid == 0) {
-        offs[ntiles] = carry;
-        hdr[0] = carry;
+        offs[ntiles] = sat(carry);
+        hdr[0] = (uint32_t)carry;
+        hdr[4] = (uint32_t)(carry >> 32);
     }
 }
 
@@ -627,6 +823,103 @@ struct WorkQueue {
     uint32_t wave_px[kThreads / 64];
 };
 
+// 16-pixel tiles keep a batch's records array-of-structures with everything that depends on the
+// triangle alone worked out ONCE by the record's thread: the nine edge constants of mu.pyx:11-21
+// and the refined reciprocals of the three denominators (raster_math.h (2)).  A sample then costs
+// six 16-byte LDS reads and ~100 vector instructions instead of twelve 4-byte reads and ~140
+// (T-Rex 1024^2's raster launch is bound by the vector pipes: 3.6 M instructions x 4 cycles over
+// 1024 SIMDs).  96 bytes per record, 128 records per batch (12 KB: eight workgroups per CU).
+struct __attribute__((aligned(16))) Rec16 {
+    float x0, y0, x1, y1;
+    float x2, y2, z0, z1;
+    float z2; uint32_t low, box_xy, box_wh;      // low word of the record's depth keys; box_wh bit 31:
+                                                 // denominators inside the division window
+    float l01, l02, l11, l12;
+    float l21, l22, l03, l13;
+    float l23, r1, r2, r3;
+};
+static_assert(sizeof(Rec16) == 96, "six 16-byte pieces");
+constexpr int kBatch16 = 128;
+constexpr uint32_t kRecFast = 0x80000000u;
+
+CR_DEV void put_rec16(Rec16 *dst, const TriXYZ &t, uint32_t low, uint32_t box_xy, uint32_t box_wh)
+{
+    const TriSetup s = make_setup(t, true);
+    float4 *d = reinterpret_cast<float4 *>(dst);
+    d[0] = make_float4(t.x0, t.y0, t.x1, t.y1);
+    d[1] = make_float4(t.x2, t.y2, t.z0, t.z1);
+    d[2] = make_float4(t.z2, __uint_as_float(low), __uint_as_float(box_xy),
+                       __uint_as_float(box_wh | (s.fast ? kRecFast : 0u)));
+    d[3] = make_float4(s.l01, s.l02, s.l11, s.l12);
+    d[4] = make_float4(s.l21, s.l22, s.l03, s.l13);
+    d[5] = make_float4(s.l23, s.r1, s.r2, s.r3);
+}
+
+// A record's sample at pixel (X, Y): same operations as fragment() — the numerators of mu.pyx:34
+// from the stored edge constants, then the three correctly rounded quotients.
+struct Rec16Regs {
+    float4 a, b, c, d, e, f;
+};
+CR_DEV Rec16Regs load_rec16(const Rec16 *r)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(r);
+    return Rec16Regs{p[0], p[1], p[2], p[3], p[4], p[5]};
+}
+CR_DEV bool fragment16(const Rec16Regs &R, int X, int Y, unsigned long long &key)
+{
+    TriSetup s;
+    s.x0 = R.a.x; s.y0 = R.a.y; s.x1 = R.a.z; s.y1 = R.a.w;
+    s.x2 = R.b.x; s.y2 = R.b.y; s.z0 = R.b.z; s.z1 = R.b.w;
+    s.z2 = R.c.x;
+    s.l01 = R.d.x; s.l02 = R.d.y; s.l11 = R.d.z; s.l12 = R.d.w;
+    s.l21 = R.e.x; s.l22 = R.e.y; s.l03 = R.e.z; s.l13 = R.e.w;
+    s.l23 = R.f.x; s.r1 = R.f.y; s.r2 = R.f.z; s.r3 = R.f.w;
+    s.rej1 = s.rej2 = s.rej3 = 0.0f;
+    s.fast = (__float_as_uint(R.c.w) & kRecFast) != 0;
+    float n1, n2, n3;
+    numerators(s, X, Y, n1, n2, n3);
+    float b1, b2, b3;
+    quotients(s, n1, n2, n3, true, b1, b2, b3);
+    if (b1 < 0.0f || b2 < 0.0f || b3 < 0.0f) return false;     // .pyx:215-216 (NaN passes)
+    const float z = interp(s.z0, s.z1, s.z2, b1, b2, b3);
+    if (z != z) return false;                                  // .pyx:220
+    key = make_key(zord(z), __float_as_uint(R.c.y));
+    return true;
+}
+
+// The winner's z, colour and normal with the barycentrics taken from its LDS record (edge
+// constants and reciprocals are there already) and colour / normal gathered by triangle index:
+// the operations of shade_and_store on the same inputs (.pyx:219, 226-242), without its gather
+// of the projected vertices and its nine edge constants.
+CR_DEV void shade16_store(const Rec16Regs &R, const float *__restrict__ col, const float *__restrict__ nrm,
+                          uint32_t tri, int X, int Y, size_t pix,
+                          float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb)
+{
+    float c[9], n[9];
+    load9(col + (size_t)tri * 9, c);
+    load9(nrm + (size_t)tri * 9, n);
+    TriSetup s;
+    s.x0 = R.a.x; s.y0 = R.a.y; s.x1 = R.a.z; s.y1 = R.a.w;
+    s.x2 = R.b.x; s.y2 = R.b.y; s.z0 = R.b.z; s.z1 = R.b.w;
+    s.z2 = R.c.x;
+    s.l01 = R.d.x; s.l02 = R.d.y; s.l11 = R.d.z; s.l12 = R.d.w;
+    s.l21 = R.e.x; s.l22 = R.e.y; s.l03 = R.e.z; s.l13 = R.e.w;
+    s.l23 = R.f.x; s.r1 = R.f.y; s.r2 = R.f.z; s.r3 = R.f.w;
+    s.rej1 = s.rej2 = s.rej3 = 0.0f;
+    s.fast = (__float_as_uint(R.c.w) & kRecFast) != 0;
+    float n1, n2, n3, b1, b2, b3;
+    numerators(s, X, Y, n1, n2, n3);
+    quotients(s, n1, n2, n3, true, b1, b2, b3);
+    zb[pix] = interp(s.z0, s.z1, s.z2, b1, b2, b3);
+    float *cp = cb + pix * 3, *np_ = nb + pix * 3;
+    cp[0] = interp(c[0], c[3], c[6], b1, b2, b3);
+    cp[1] = interp(c[1], c[4], c[7], b1, b2, b3);
+    cp[2] = interp(c[2], c[5], c[8], b1, b2, b3);
+    np_[0] = interp(n[0], n[3], n[6], b1, b2, b3);
+    np_[1] = interp(n[1], n[4], n[7], b1, b2, b3);
+    np_[2] = interp(n[2], n[5], n[8], b1, b2, b3);
+}
+
 // The record a 16-lane group is sweeping.  T = TriXYZ (small records: the edge constants are
 // hoisted by the compiler) or TriSetup (large records: with the two division shortcuts).
 template <typename T>
@@ -715,113 +1008,382 @@ CR_DEV void coarse_cull(WorkQueue &q, const uint32_t *wo, int total, int tid,
 }
 
 #ifdef CRENDER_STAMPS
-// Diagnostic build only: per-tile phase timestamps (s_memrealtime, 100 MHz, one clock for the
-// whole device — s_memtime has a base per XCD / clock domain) written to a buffer of their
-// own that no kernel reads.  8 words per tile: t_start, t_ready, t_swept, t_end, list length,
-// (unused), (unused), XCC id.
+// Diagnostic build only: per-workgroup phase timestamps (s_memrealtime, 100 MHz, one clock for
+// the whole device — s_memtime has a base per XCD / clock domain) written to a buffer of their
+// own that no kernel reads.  16 words per workgroup of the raster grid: t_start, t_ready, t_swept,
+// t_end, list length, t_loads, t_queue, XCC id, tile, quadrant + 1.
 __device__ unsigned long long *g_stamps = nullptr;
 #define CR_STAMP(slot)                                                             \
     do {                                                                           \
-        if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)tile * 8 + (slot)] = wall_clock64(); \
+        if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64(); \
     } while (0)
 #else
 #define CR_STAMP(slot) do { } while (0)
 #endif
 
+// Background of a tile rectangle (fused clear): z = 1e6, colour = normal = 0, winner = -1.
+// Full-width rows of 16-byte aligned planes go out as float4 stores (a 16-pixel tile is 448 of
+// them, two per thread, against seven dword stores per pixel); anything else pixel by pixel.
+// Every address is a uniform base (the rectangle's first pixel) plus a 32-bit per-thread offset:
+// the empty tiles are three quarters of a 1024^2 frame's workgroups and their instruction count
+// is part of the launch's (64-bit per-thread address arithmetic tripled it).
+template <int TS>
+CR_DEV void clear_rect(float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
+                       int32_t *__restrict__ win, int W, int X0, int Y0, int X1, int Y1, bool vec, int tid)
+{
+    const size_t p0 = (size_t)Y0 * W + X0;
+    float *z0 = zb + p0, *c0 = cb + p0 * 3, *n0 = nb + p0 * 3;
+    int32_t *w0 = win ? win + p0 : nullptr;
+    const uint32_t t = (uint32_t)tid, uW = (uint32_t)W;
+    // (the constants are made here, opaquely: hoisted to the top of the kernel they would hold
+    // registers across the whole sweep)
+    float z1 = 1e6f, o1 = 0.0f;
+    asm volatile("" : "+v"(z1), "+v"(o1));
+    const float4 zv = make_float4(z1, z1, z1, z1), ov = make_float4(o1, o1, o1, o1);
+    const int4 wv = make_int4(-1, -1, -1, -1);
+    if (vec && X1 - X0 == TS) {
+        constexpr uint32_t ZQ = TS / 4, CQ = 3 * TS / 4;          // float4 per row: z, colour / normal
+        const uint32_t rows = (uint32_t)(Y1 - Y0);
+        if (TS == 16 && rows == 16) {
+            // thread t: piece t (z plane for t < 64, else colour piece t - 64) and piece t + 256
+            // (normal piece t, t < 192)
+            const uint32_t r1 = t / CQ, off1 = r1 * uW * 3 + (t - r1 * CQ) * 4;
+            if (t < 64) {
+                const uint32_t off0 = (t >> 2) * uW + (t & 3) * 4;
+                *reinterpret_cast<float4 *>(z0 + off0) = zv;
+                if (w0) *reinterpret_cast<int4 *>(w0 + off0) = wv;
+            } else {
+                const uint32_t k = t - 64, r0 = k / CQ;
+                *reinterpret_cast<float4 *>(c0 + r0 * uW * 3 + (k - r0 * CQ) * 4) = ov;
+            }
+            if (t < 192) *reinterpret_cast<float4 *>(n0 + off1) = ov;
+            return;
+        }
+        for (uint32_t i = t; i < rows * ZQ; i += kThreads) {
+            const uint32_t r = i / ZQ, off = r * uW + (i - r * ZQ) * 4;
+            *reinterpret_cast<float4 *>(z0 + off) = zv;
+            if (w0) *reinterpret_cast<int4 *>(w0 + off) = wv;
+        }
+        for (uint32_t i = t; i < rows * CQ; i += kThreads) {
+            const uint32_t r = i / CQ, off = r * uW * 3 + (i - r * CQ) * 4;
+            *reinterpret_cast<float4 *>(c0 + off) = ov;
+            *reinterpret_cast<float4 *>(n0 + off) = ov;
+        }
+        return;
+    }
+    const uint32_t w = (uint32_t)(X1 - X0), n = w * (uint32_t)(Y1 - Y0);
+    for (uint32_t p = t; p < n; p += kThreads) {
+        const uint32_t dy = p / w, off = dy * uW + (p - dy * w);
+        z0[off] = z1;
+        c0[off * 3] = o1; c0[off * 3 + 1] = o1; c0[off * 3 + 2] = o1;
+        n0[off * 3] = o1; n0[off * 3 + 1] = o1; n0[off * 3 + 2] = o1;
+        if (w0) w0[off] = -1;
+    }
+}
+
+// Per-frame view of the plan's tile lists, of the heavy-tile hand-off and of the dispatch-order
+// hint (k_raster side).
+struct TileLists {
+    const uint32_t *offs;       // scan path: list offsets into `entries`; null = direct bins
+    const uint32_t *count;      // direct bins: list lengths of THIS frame (never written here)
+    uint32_t *count_next;       // the other parity's counters: zeroed here for the next frame
+    const uint32_t *entries;    // scan path: triangle indices
+    const float4 *bins;         // direct bins: [ntiles][capacity] entries (BinEntry, three pieces each)
+    uint32_t capacity;
+    uint32_t T;                 // triangle count: list entries >= T (stale workspace) are ignored
+    // heavy tiles (see register_heavy): null / 0 when the launch has no helper workgroups
+    uint32_t *heavy_flag, *heavy_slots, *heavy_ctr_next;
+    int nhelp;                  // 3 * hmax helper workgroups
+    // dispatch order (see build_order): null when the launch is not ordered
+    const uint32_t *order, *hint, *hint_bad;
+    uint32_t *order_next, *hint_next, *hint_bad_next;
+    unsigned char *grouped_next;
+    int vec_clear;              // planes 16-byte aligned and W % 4 == 0
+};
+
+// One record of a tile's list: projected vertices, triangle index, pixel box.  false = a stale
+// index (beyond the frame's triangle count): no work.
+CR_DEV bool load_record(const TileLists &L, const float *__restrict__ proj, const Geom &G, uint32_t idx,
+                        uint32_t &id, TriXYZ &t, uint32_t &ebx, uint32_t &eby)
+{
+    if (L.offs) {
+        id = L.entries[idx];
+        if (id >= L.T) return false;
+        t = load_tri(proj + (size_t)id * 9);
+        int xl, xr, yt, yb;
+        pixel_box(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2, G.W, G.H, xl, xr, yt, yb);
+        ebx = (uint32_t)xl | ((uint32_t)xr << 16);
+        eby = (uint32_t)yt | ((uint32_t)yb << 16);
+        return true;
+    }
+    const float4 *e = L.bins + (size_t)idx * 3;          // (BinEntry: 32- and 64-pixel tiles)
+    const float4 e0 = e[0], e1 = e[1], e2 = e[2];
+    t = TriXYZ{e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x};
+    id = __float_as_uint(e2.y);
+    ebx = __float_as_uint(e2.z);
+    eby = __float_as_uint(e2.w);
+    return id < L.T;
+}
+
+// ---- dispatch order from the previous frame's coverage -------------------------------------
+// The dispatcher starts workgroups strictly in grid order and a workgroup slot is held until its
+// stores are acknowledged, so in raster order the covered tiles of T-Rex 1024^2 (the middle rows
+// of the frame) started 1-3 us into the launch, behind a full chip of background tiles whose
+// 28 MB of clears also doubled the latency of every load the covered tiles then issued
+// (in-kernel stamps, profiles/r02).  Consecutive frames cover almost the same tiles, so each
+// raster launch leaves an ORDER for the next launch on the same plan: the tiles it found covered
+// first (longest lists first), one workgroup each, then the empty tiles in groups of kGroup per
+// workgroup, which are cleared without a look at their lists.  The order is only a hint about speed — it is always a permutation of the tiles
+// and every workgroup reads the actual list length of each tile it is handed, rasterizing it
+// if it is not empty after all — so a stale order (another model, a first frame) costs time,
+// never pixels.  Built by the launch's first workgroup from this frame's counters, which no
+// workgroup writes; read by the next launch (ping-pong buffers).
+constexpr int kGroup = 8;      // empty tiles cleared per workgroup of the order's last section
+constexpr int kOrderMaxTiles = 8192;   // the builder keeps one byte per tile in the 13 KB of the batch queue
+CR_DEV void build_order(const uint32_t *__restrict__ count, int ntx, int nty,
+                        uint32_t *__restrict__ order_next, unsigned char *__restrict__ grouped_next,
+                        uint32_t *__restrict__ hint_next, uint32_t *scr)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = ntx * nty;
+    // Step 1: each tile's class into LDS, one byte per tile (coalesced loads of the counters, all
+    // in flight).  Then the stable partition over contiguous chunks of the class bytes.  The
+    // launch cannot end before this workgroup does: it has to stay a few microseconds (a version
+    // that also looked at every empty tile's eight neighbours, to give tiles next to the model a
+    // workgroup of their own, took as long as the whole launch).
+    // classes: 0 heavy, 1 medium, 2 light lists (a workgroup each); 4 empty (cleared in groups)
+    unsigned char *cls = reinterpret_cast<unsigned char *>(scr + 32);
+    (void)nty;
+    for (int i = tid; i < ntiles; i += kThreads) {
+        const uint32_t c = count[i];
+        cls[i] = (unsigned char)(c >= kHeavyAt ? 0 : c >= 8u ? 1 : c ? 2 : 4);
+    }
+    __syncthreads();
+    auto cls_of = [&](int i) { return (int)cls[i]; };
+    // contiguous chunk of tiles per thread: the partition is stable, so each class keeps raster
+    // order (tiles that are cleared together stay neighbours in memory: scattered, the clears of
+    // T-Rex 1024^2 alone took 14 us instead of 7)
+    const int chunk = (ntiles + kThreads - 1) / kThreads;
+    const int i0 = tid * chunk, i1 = i0 + chunk < ntiles ? i0 + chunk : ntiles;
+    uint32_t n[5] = {0, 0, 0, 0, 0};
+    for (int i = i0; i < i1; ++i) {
+        const int k = cls_of(i);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) n[c] += (k == c);
+    }
+    uint32_t incl[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        incl[c] = n[c];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl[c], d, 64);
+            if (lane >= d) incl[c] += v;
+        }
+        if (lane == 63) scr[wave * 5 + c] = incl[c];
+    }
+    __syncthreads();
+    uint32_t off[5], tot[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) {
+            const uint32_t t = scr[w * 5 + c];
+            if (w < wave) before += t;
+            total += t;
+        }
+        tot[c] = total;
+        off[c] = before + incl[c] - n[c];
+    }
+    uint32_t basec = 0;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) { off[c] += basec; basec += tot[c]; }
+    for (int i = i0; i < i1; ++i) {
+        const int k = cls_of(i);
+        uint32_t pos = 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            if (k == c) pos = off[c]++;
+        order_next[pos] = (uint32_t)i;
+        grouped_next[i] = k == 4;
+    }
+    if (tid == 0) {
+        const uint32_t ncov = tot[0] + tot[1] + tot[2];
+        hint_next[1] = ncov + tot[3];                       // tiles with a workgroup of their own
+        hint_next[2] = (tot[4] + kGroup - 1) / kGroup;      // workgroups that clear kGroup tiles each
+        hint_next[0] = ncov ? 1u : 0u;     // an empty frame says nothing about the next one
+    }
+}
+
 template <int TS, bool CLEAR>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? CR_WPE16 : TS == 32 ? CR_WPE32 : 1)))
 void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
-              const float *__restrict__ nrm, const uint32_t *__restrict__ offs,
-              uint32_t *__restrict__ cursor, const uint32_t *__restrict__ entries, uint32_t capacity,
+              const float *__restrict__ nrm, TileLists L,
               float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
-              int32_t *__restrict__ win, Geom G, int dbg)
+              int32_t *__restrict__ win, Geom G, int dbg_arg)
 {
     __shared__ unsigned long long key[TS * TS];
-    __shared__ WorkQueue q;
-
-    int tile = (dbg & 8) ? xcd_band_tile(blockIdx.x, G.ntiles) : (int)blockIdx.x;
-    // Large grids: scatter the dispatch order (block b -> tile b * stride mod ntiles) so that a
-    // band of covered tiles is spread over the whole launch instead of arriving together
-    // (T-Rex 8192^2: 0.446 -> 0.402 ms).  Small grids are faster in raster order
-    // (T-Rex 1024^2: 24.7 vs 29.1 us), so the scatter starts at 32768 tiles.
-    if ((G.ntiles >= 32768) != ((dbg & 256) != 0)) {
-        // (b * stride) mod ntiles, the product below 2^48: quotient from a double multiply
-        // (exact product, at most one off after rounding), remainder fixed up
-        const unsigned long long P = (unsigned long long)blockIdx.x * (unsigned)G.tile_stride;
-        const unsigned long long qd = (unsigned long long)((double)P * G.inv_ntiles);
-        long long r = (long long)(P - qd * (unsigned)G.ntiles);
-        if (r < 0) r += G.ntiles;
-        if (r >= G.ntiles) r -= G.ntiles;
-        tile = (int)r;
-    }
-    const int ty = G.ntx_magic ? (int)__umulhi((uint32_t)tile, G.ntx_magic) : tile / G.ntx;
-    int tx = tile - ty * G.ntx;
-    // Workgroup b runs on XCD b % 8 and, there, on shader engine (b / 8) % 4, and the dispatcher
-    // places workgroups strictly in order.  With a tile row that is a multiple of 32 tiles a
-    // tile COLUMN would always meet the same (XCD, engine) pair: the pairs that own the columns
-    // under the model fill up with long-lived workgroups and stall the whole dispatch while a
-    // third of the chip's workgroup slots stand free (in-kernel timeline, scripts/stamps.py:
-    // ~900 of T-Rex's 1140 covered tiles in flight, the rest trickling in).  Rotating row ty
-    // by 9 * ty columns walks every pair through every column: all covered tiles are in flight
-    // after 3 us (T-Rex 1024^2 raster 24.0 -> 21.6 us, 73.3k -> 79.2k frames/s; the larger
-    // frames gain 0-2 %).  CRENDER_DEBUG bit 512 turns it off.
-    if (!(dbg & 512)) {
-        const int t = tx + 9 * ty;
-        tx = G.ntx_magic ? t - (int)__umulhi((uint32_t)t, G.ntx_magic) * G.ntx : t % G.ntx;
-        tile = ty * G.ntx + tx;
-    }
-    const int X0 = tx * TS, Y0 = G.y0 + ty * TS;
-    const int X1 = (X0 + TS < G.W) ? (X0 + TS) : G.W;
-    const int Y1 = (Y0 + TS < G.y1) ? (Y0 + TS) : G.y1;
+    // the batch: records array-of-structures on 16-pixel tiles (Rec16), else the WorkQueue
+    constexpr size_t kQueueBytes = TS == 16 ? sizeof(Rec16) * kBatch16 + sizeof(uint32_t) * (kThreads + 8)
+                                            : sizeof(WorkQueue);
+    __shared__ __attribute__((aligned(16))) unsigned char qraw[kQueueBytes];
+    WorkQueue &q = *reinterpret_cast<WorkQueue *>(qraw);                 // (TS != 16 only)
+    Rec16 *recs = reinterpret_cast<Rec16 *>(qraw);                       // (TS == 16 only)
+    uint32_t *scan16 = reinterpret_cast<uint32_t *>(qraw + sizeof(Rec16) * kBatch16);
+    uint32_t *wave16 = scan16 + kThreads;
+    constexpr int kBatch = TS == 16 ? kBatch16 : kThreads;
+#ifdef CRENDER_DEV_KNOBS
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
-    CR_STAMP(0);
-#ifdef CRENDER_STAMPS
-    // XCC_ID (hwreg 20, bits 0..3)
-    if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)tile * 8 + 7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-#endif
-    // the tile's triangle list: a run of the scanned bin array, or (direct bins, offs == null)
-    // a fixed-capacity slab whose fill count k_setup left in cursor[tile]
-    uint32_t beg, end;
-    if (offs) {
-        beg = offs[tile];
-        end = offs[tile + 1];
-        if (end > capacity) end = capacity;
-        if (beg > end) beg = end;
-    } else {
-        const uint32_t n = cursor[tile];
-        beg = (uint32_t)tile * capacity;
-        end = beg + (n < capacity ? n : capacity);
+    // ---- which tile, and which part of it --------------------------------------------------
+    // grid = [order builder, if ordered][3 * hmax helpers][ntiles main workgroups, one tile each]
+    int b = (int)blockIdx.x;
+    if (L.order_next) {
+        if (b == 0) {
+            build_order(L.count, G.ntx, G.nty, L.order_next, L.grouped_next, L.hint_next, reinterpret_cast<uint32_t *>(qraw));
+            return;
+        }
+        b -= 1;
     }
-    if (dbg & 1) end = beg;   // ablation: no coverage work
-
-    if (beg == end) {
-        // nothing to rasterize here: the tile keeps its content, or (fused clear) becomes
-        // background — no key plane, no barriers
-        if (CLEAR) {
-            for (int p = tid; p < TS * TS; p += kThreads) {
-                const int x = X0 + (p % TS), y = Y0 + (p / TS);
-                if (x >= X1 || y >= Y1) continue;
-                const size_t pix = (size_t)y * G.W + x;
-                zb[pix] = 1e6f;
-                cb[pix * 3] = 0.0f; cb[pix * 3 + 1] = 0.0f; cb[pix * 3 + 2] = 0.0f;
-                nb[pix * 3] = 0.0f; nb[pix * 3 + 1] = 0.0f; nb[pix * 3 + 2] = 0.0f;
-                if (win) win[pix] = -1;
+    const bool helper = b < L.nhelp;
+    int quad = -1;               // -1 = the whole tile, 0..3 = one 8x8 quadrant of a heavy tile
+    int tile;
+    if (helper) {
+        // quadrant 1..3 of the heavy tile registered in this workgroup's slot, if any
+        const uint32_t v = L.heavy_slots[b];
+        if (v == 0) return;                        // (same word for every thread: uniform)
+        tile = (int)v - 1;
+        quad = 1 + b % 3;
+    } else {
+        const int m = b - L.nhelp;
+        if (m == 0 && tid == 0) {
+            if (L.heavy_ctr_next) *L.heavy_ctr_next = 0;
+            *L.hint_bad_next = 0;
+        }
+        if (L.order && L.hint[0] && !*L.hint_bad) {
+            const int ns = (int)L.hint[1], ng = (int)L.hint[2];
+            if (m < ns) {
+                tile = (int)L.order[m];
+            } else {
+                // the order's last section: up to kGroup empty tiles per workgroup, cleared with two
+                // float4 stores per thread and tile (no list to look at: the binning pass vouches
+                // for their emptiness, see first_entry_of)
+                if (m >= ns + ng) return;
+                const int first = ns + (m - ns) * kGroup;
+                const int ntl = G.ntiles - first < kGroup ? G.ntiles - first : kGroup;
+                uint32_t tl[kGroup];
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) tl[j] = j < ntl ? L.order[first + j] : 0u;
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) {
+                    if (j >= ntl) break;
+                    const uint32_t tu = tl[j];
+                    const int gy = G.ntx_magic ? (int)__umulhi(tu, G.ntx_magic) : (int)tu / G.ntx;
+                    const int gx = (int)tu - gy * G.ntx;
+                    const int x0 = gx * TS, y0 = G.y0 + gy * TS;
+                    if (tid == 0) L.count_next[tu] = 0;
+                    if (CLEAR)
+                        clear_rect<TS>(zb, cb, nb, win, G.W, x0, y0, (x0 + TS < G.W) ? x0 + TS : G.W,
+                                       (y0 + TS < G.y1) ? y0 + TS : G.y1, L.vec_clear != 0, tid);
+                }
+                return;
+            }
+        } else {
+            tile = (dbg & 8) ? xcd_band_tile(m, G.ntiles) : m;
+            // Large grids: scatter the dispatch order (block b -> tile b * stride mod ntiles) so
+            // that a band of covered tiles is spread over the whole launch instead of arriving
+            // together (T-Rex 8192^2: 0.446 -> 0.402 ms).  Small grids are faster in raster order
+            // (T-Rex 1024^2: 24.7 vs 29.1 us), so the scatter starts at 32768 tiles.
+            if ((G.ntiles >= 32768) != ((dbg & 256) != 0)) {
+                // (b * stride) mod ntiles, the product below 2^48: quotient from a double multiply
+                // (exact product, at most one off after rounding), remainder fixed up
+                const unsigned long long P = (unsigned long long)m * (unsigned)G.tile_stride;
+                const unsigned long long qd = (unsigned long long)((double)P * G.inv_ntiles);
+                long long r = (long long)(P - qd * (unsigned)G.ntiles);
+                if (r < 0) r += G.ntiles;
+                if (r >= G.ntiles) r -= G.ntiles;
+                tile = (int)r;
+            }
+            // Workgroup b runs on XCD b % 8 and, there, on shader engine (b / 8) % 4, and the
+            // dispatcher places workgroups strictly in order.  With a tile row that is a multiple
+            // of 32 tiles a tile COLUMN would always meet the same (XCD, engine) pair: the pairs
+            // that own the columns under the model fill up with long-lived workgroups and stall
+            // the whole dispatch while a third of the chip's workgroup slots stand free.  Rotating
+            // row ty by 9 * ty columns walks every pair through every column (T-Rex 1024^2 raster
+            // 24.0 -> 21.6 us; the larger frames gain 0-2 %).
+            if (!(dbg & 512)) {
+                const int ty = G.ntx_magic ? (int)__umulhi((uint32_t)tile, G.ntx_magic) : tile / G.ntx;
+                const int t = tile - ty * G.ntx + 9 * ty;
+                const int tx = G.ntx_magic ? t - (int)__umulhi((uint32_t)t, G.ntx_magic) * G.ntx : t % G.ntx;
+                tile = ty * G.ntx + tx;
             }
         }
-        CR_STAMP(3);
-        return;   // cursor[tile] is already zero
     }
+    const int ty = G.ntx_magic ? (int)__umulhi((uint32_t)tile, G.ntx_magic) : tile / G.ntx;
+    const int tx = tile - ty * G.ntx;
+    int X0 = tx * TS, Y0 = G.y0 + ty * TS;
+    int X1 = (X0 + TS < G.W) ? (X0 + TS) : G.W;
+    int Y1 = (Y0 + TS < G.y1) ? (Y0 + TS) : G.y1;
 
-    // first batch of the tile's list: index + projected vertices straight into registers
-    uint32_t cur_id = 0;
-    TriXYZ cur_t{};
-    bool cur_ok = beg + tid < end;
-    if (cur_ok) {
-        cur_id = entries[beg + tid];
-        cur_t = load_tri(proj + (size_t)cur_id * 9);
+    CR_STAMP(0);
+#ifdef CRENDER_STAMPS
+    if (g_stamps && threadIdx.x == 0) {
+        g_stamps[(size_t)blockIdx.x * 16 + 7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID
+        g_stamps[(size_t)blockIdx.x * 16 + 8] = (unsigned long long)tile;
+        g_stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memtime();
     }
+#endif
+    // the tile's triangle list: a run of the scanned index array, or (direct bins, offs == null)
+    // a fixed-capacity slab of entries whose fill count k_setup_wave left in count[tile]
+    uint32_t beg, end;
+    if (L.offs) {
+        beg = L.offs[tile];
+        end = L.offs[tile + 1];
+        if (end > L.capacity) end = L.capacity;
+        if (beg > end) beg = end;
+    } else {
+        const uint32_t n = L.count[tile];
+        beg = (uint32_t)tile * L.capacity;
+        end = beg + (n < L.capacity ? n : L.capacity);
+    }
+    if (!helper) {
+        if (L.heavy_flag && L.heavy_flag[tile]) quad = 0;
+        // the other parity's counter of this tile: zero for the next frame
+        if (tid == 0) L.count_next[tile] = 0;
+    }
+    if (quad >= 0) {
+        constexpr int HS = TS / 2;
+        X0 += (quad & 1) * HS; Y0 += (quad >> 1) * HS;
+        if (X1 > X0 + HS) X1 = X0 + HS;
+        if (Y1 > Y0 + HS) Y1 = Y0 + HS;
+        if (X1 < X0) X1 = X0;
+        if (Y1 < Y0) Y1 = Y0;
+    }
+    if (dbg & 1) end = beg;   // ablation: no coverage work (development build)
+
+    const bool work = beg != end && X0 < X1 && Y0 < Y1;     // (uniform over the workgroup)
+    if (!work) {
+        // nothing to rasterize here: the rectangle keeps its content, or (fused clear) becomes
+        // background — no key plane, no barriers
+        if (CLEAR && X0 < X1 && Y0 < Y1) clear_rect<TS>(zb, cb, nb, win, G.W, X0, Y0, X1, Y1, L.vec_clear && quad < 0, tid);
+        CR_STAMP(3);
+    } else {
+    // 16-pixel tiles with direct bins (at most 65536 triangles): a depth key's low word carries
+    // the triangle index in its high half as usual and, in its low half, where the record sits
+    // in LDS — batch and slot — so that the resolve takes the winner's edge constants from there
+    const bool slotted = TS == 16 && !L.offs;
+    // first batch of the tile's list straight into registers
+    uint32_t cur_id = 0, cur_bx = 0, cur_by = 0;
+    TriXYZ cur_t{};
+    bool cur_ok = tid < kBatch && beg + tid < end;
+    if (cur_ok) cur_ok = load_record(L, proj, G, beg + tid, cur_id, cur_t, cur_bx, cur_by);
 
     // depth keys of the tile: the prior buffer value (or the cleared value) per pixel
     const unsigned long long key_clear = make_key(zord(1e6f), KEY_LOW_PRIOR);
@@ -835,15 +1397,18 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
     }
     CR_STAMP(1);
 #ifdef CRENDER_STAMPS
-    if (g_stamps && tid == 0) g_stamps[(size_t)tile * 8 + 4] = end - beg;
+    if (g_stamps && tid == 0) {
+        g_stamps[(size_t)blockIdx.x * 16 + 4] = end - beg;
+        g_stamps[(size_t)blockIdx.x * 16 + 9] = (unsigned long long)(quad + 1);
+    }
 #endif
 
-    for (uint32_t base = beg; base < end; base += kThreads) {
+    for (uint32_t base = beg; base < end; base += kBatch) {
         // ---- queue this batch: one record per thread, slot = thread index --------------
         uint32_t box_xy = 0, box_wh = 0;
         if (cur_ok) {
-            int xl, xr, yt, yb;
-            pixel_box(cur_t.x0, cur_t.y0, cur_t.x1, cur_t.y1, cur_t.x2, cur_t.y2, G.W, G.H, xl, xr, yt, yb);
+            int xl = (int)(cur_bx & 0xFFFF), xr = (int)(cur_bx >> 16);
+            int yt = (int)(cur_by & 0xFFFF), yb = (int)(cur_by >> 16);
             if (xl < X0) xl = X0;
             if (xr > X1) xr = X1;
             if (yt < Y0) yt = Y0;
@@ -853,6 +1418,8 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                 box_wh = (uint32_t)(xr - xl) | ((uint32_t)(yb - yt) << 16);
             }
         }
+        const uint32_t key_low = slotted ? ((0xFFFFu - (cur_id & 0xFFFFu)) << 16) | ((((base - beg) / kBatch) & 0xFFu) << 8) | (uint32_t)tid
+                                         : 0xFFFFFFFEu - cur_id;
 #ifdef CRENDER_STAMPS
         if (base == beg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CR_STAMP(5); }
 #endif
@@ -865,14 +1432,7 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
             const uint32_t pix_max = (dbg >> 16) & 0xFF ? (uint32_t)((dbg >> 16) & 0xFF) - 1u : kPixelPathRecords;
             if (left <= pix_max) {
                 __syncthreads();
-                if (tid < (int)left) {
-                    q.x0[tid] = cur_t.x0; q.y0[tid] = cur_t.y0; q.z0[tid] = cur_t.z0;
-                    q.x1[tid] = cur_t.x1; q.y1[tid] = cur_t.y1; q.z1[tid] = cur_t.z1;
-                    q.x2[tid] = cur_t.x2; q.y2[tid] = cur_t.y2; q.z2[tid] = cur_t.z2;
-                    q.tri[tid] = cur_id;
-                    q.box_xy[tid] = box_xy;
-                    q.box_wh[tid] = box_wh;
-                }
+                if (tid < (int)left) put_rec16(&recs[tid], cur_t, key_low, box_xy, box_wh);
                 __syncthreads();
 #ifdef CRENDER_STAMPS
                 if (base == beg) CR_STAMP(6);
@@ -880,17 +1440,16 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                 const int px = X0 + (tid & 15), py = Y0 + (tid >> 4);
                 unsigned long long best = key[tid];
                 for (uint32_t r = 0; r < left; ++r) {
-                    const uint32_t wh = q.box_wh[r];
+                    const uint32_t wh = recs[r].box_wh & ~kRecFast;
                     if (wh == 0) continue;
-                    const uint32_t xy = q.box_xy[r];
+                    const uint32_t xy = recs[r].box_xy;
                     const int bx0 = (int)(xy & 0xFFFF), by0 = (int)(xy >> 16);
                     const bool in = px >= bx0 && px < bx0 + (int)(wh & 0xFFFF) &&
                                     py >= by0 && py < by0 + (int)(wh >> 16);
                     if (!__any(in)) continue;
-                    const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
-                                   q.x2[r], q.y2[r], q.z2[r]};
+                    const Rec16Regs R = load_rec16(&recs[r]);
                     unsigned long long k;
-                    if (in && fragment(t, q.tri[r], px, py, k) && k < best) best = k;
+                    if (in && fragment16(R, px, py, k) && k < best) best = k;
                 }
                 key[tid] = best;
                 cur_ok = false;
@@ -917,17 +1476,23 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
         // previous batch's sweeps must be over before the queue is overwritten; this
         // barrier also orders the key initialisation before the first sweep
         __syncthreads();
-        q.x0[tid] = cur_t.x0; q.y0[tid] = cur_t.y0; q.z0[tid] = cur_t.z0;
-        q.x1[tid] = cur_t.x1; q.y1[tid] = cur_t.y1; q.z1[tid] = cur_t.z1;
-        q.x2[tid] = cur_t.x2; q.y2[tid] = cur_t.y2; q.z2[tid] = cur_t.z2;
-        q.tri[tid] = cur_id;
-        q.box_xy[tid] = box_xy;
-        q.box_wh[tid] = box_wh;
-        q.blk_scan[tid] = incl - my_blocks;
-        if (lane == 63) q.wave_blocks[wave] = incl;
-        if constexpr (either) {
-            q.px_scan[tid] = incl_px - my_px;
-            if (lane == 63) q.wave_px[wave] = incl_px;
+        if constexpr (TS == 16) {
+            if (tid < kBatch) put_rec16(&recs[tid], cur_t, key_low, box_xy, box_wh);
+            scan16[tid] = incl - my_blocks;
+            if (lane == 63) wave16[wave] = incl;
+        } else {
+            q.x0[tid] = cur_t.x0; q.y0[tid] = cur_t.y0; q.z0[tid] = cur_t.z0;
+            q.x1[tid] = cur_t.x1; q.y1[tid] = cur_t.y1; q.z1[tid] = cur_t.z1;
+            q.x2[tid] = cur_t.x2; q.y2[tid] = cur_t.y2; q.z2[tid] = cur_t.z2;
+            q.tri[tid] = cur_id;
+            q.box_xy[tid] = box_xy;
+            q.box_wh[tid] = box_wh;
+            q.blk_scan[tid] = incl - my_blocks;
+            if (lane == 63) q.wave_blocks[wave] = incl;
+            if constexpr (either) {
+                q.px_scan[tid] = incl_px - my_px;
+                if (lane == 63) q.wave_px[wave] = incl_px;
+            }
         }
         __syncthreads();  // queue complete
 #ifdef CRENDER_STAMPS
@@ -935,12 +1500,9 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
 #endif
 
         // next batch: issue its loads now, they complete under the sweeps
-        const uint32_t nxt = base + kThreads + tid;
-        cur_ok = nxt < end;
-        if (cur_ok) {
-            cur_id = entries[nxt];
-            cur_t = load_tri(proj + (size_t)cur_id * 9);
-        }
+        const uint32_t nxt = base + kBatch + tid;
+        cur_ok = tid < kBatch && nxt < end;
+        if (cur_ok) cur_ok = load_record(L, proj, G, nxt, cur_id, cur_t, cur_bx, cur_by);
 
         // ---- sweep: the batch's work items, flattened and split evenly -------------------------
         {
@@ -948,9 +1510,9 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
             uint32_t wo[kThreads / 64 + 1];
             wo[0] = 0;
 #pragma unroll
-            for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + q.wave_blocks[w];
+            for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + (TS == 16 ? wave16[w] : q.wave_blocks[w]);
             const int total = (int)wo[kThreads / 64];
-            const int nrec = (int)((end - base) < (uint32_t)kThreads ? (end - base) : (uint32_t)kThreads);
+            const int nrec = (int)((end - base) < (uint32_t)kBatch ? (end - base) : (uint32_t)kBatch);
             // Per-pixel sweep: every pixel of every clipped box is one work item; thread t takes
             // items t, t + 256, ...  All lanes work on a sample that lies in its box (a 4x4 block
             // of a small box is mostly empty: 71 % of T-Rex 1024^2's block lanes were inside their
@@ -975,21 +1537,31 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
                     } else {
                         r = find_record(scan, wo_, e, i);
                     }
-                    const uint32_t xy = q.box_xy[r];
-                    const int bw = box_w(q.box_wh[r]);
-                    // i / bw for i < 1024, bw <= 32: the approximate reciprocal is exact enough
-                    const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bw));
-                    const int x = (int)(xy & 0xFFFF) + ((int)i - dy * bw), y = (int)(xy >> 16) + dy;
-                    const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
-                                   q.x2[r], q.y2[r], q.z2[r]};
-                    unsigned long long k;
-                    if (fragment(t, q.tri[r], x, y, k)) lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                    if constexpr (TS == 16) {
+                        const Rec16Regs R = load_rec16(&recs[r]);
+                        const uint32_t xy = __float_as_uint(R.c.z);
+                        const int bw = box_w(__float_as_uint(R.c.w));
+                        const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bw));
+                        const int x = (int)(xy & 0xFFFF) + ((int)i - dy * bw), y = (int)(xy >> 16) + dy;
+                        unsigned long long k;
+                        if (fragment16(R, x, y, k)) lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                    } else {
+                        const uint32_t xy = q.box_xy[r];
+                        const int bw = box_w(q.box_wh[r]);
+                        // i / bw for i < 1024, bw <= 32: the approximate reciprocal is exact enough
+                        const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bw));
+                        const int x = (int)(xy & 0xFFFF) + ((int)i - dy * bw), y = (int)(xy >> 16) + dy;
+                        const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
+                                       q.x2[r], q.y2[r], q.z2[r]};
+                        unsigned long long k;
+                        if (fragment(t, q.tri[r], x, y, k)) lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                    }
                 }
             };
             bool small_by_pixel = false;    // 32-pixel tiles: small records go per pixel too
             if constexpr (either) small_by_pixel = total < 16 * nrec && !(dbg & 8192);
             if constexpr (per_pixel) {
-                sweep_pixels(q.blk_scan, wo, total);
+                sweep_pixels(scan16, wo, total);
             } else if (small_by_pixel) {
                 uint32_t wop[kThreads / 64 + 1];
                 wop[0] = 0;
@@ -1129,10 +1701,14 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
     __syncthreads();
 
     CR_STAMP(2);
-    // resolve: every pixel of the tile is written at most once (exactly once if CLEAR)
-    for (int p = tid; p < TS * TS; p += kThreads) {
-        const int x = X0 + (p % TS), y = Y0 + (p / TS);
+    // resolve: every pixel of the rectangle is written at most once (exactly once if CLEAR).
+    // A quadrant's 64 pixels are taken by the first wavefront in rows of 8.
+    const int npx = quad >= 0 ? (TS / 2) * (TS / 2) : TS * TS;
+    for (int p0 = tid; p0 < npx; p0 += kThreads) {
+        const int dx = quad >= 0 ? p0 % (TS / 2) : p0 % TS, dy = quad >= 0 ? p0 / (TS / 2) : p0 / TS;
+        const int x = X0 + dx, y = Y0 + dy;
         if (x >= X1 || y >= Y1) continue;
+        const int p = dy * TS + dx;
         const size_t pix = (size_t)y * G.W + x;
         const uint32_t low = (uint32_t)key[p];
         if (low == KEY_LOW_PRIOR) {
@@ -1144,8 +1720,17 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
             }
             continue;
         }
-        const uint32_t id = 0xFFFFFFFEu - low;
-        if (dbg & 2) {   // ablation: no shading
+        uint32_t id = 0xFFFFFFFEu - low;
+        if (slotted) {
+            id = 0xFFFFu - (low >> 16);
+            if (((low >> 8) & 0xFFu) == (((end - beg - 1) / kBatch) & 0xFFu) && !(dbg & 2)) {
+                // the winner's record is still in LDS (it came with the last batch)
+                shade16_store(load_rec16(&recs[low & 0xFFu]), col, nrm, id, x, y, pix, zb, cb, nb);
+                if (win) win[pix] = (int32_t)id;
+                continue;
+            }
+        }
+        if (dbg & 2) {   // ablation: no shading (development build)
             zb[pix] = (float)id;
             cb[pix * 3] = 1.0f; cb[pix * 3 + 1] = 1.0f; cb[pix * 3 + 2] = 1.0f;
             nb[pix * 3] = 1.0f; nb[pix * 3 + 1] = 1.0f; nb[pix * 3 + 2] = 1.0f;
@@ -1154,10 +1739,19 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
         shade_and_store(proj, col, nrm, id, x, y, pix, zb, cb, nb);
         if (win) win[pix] = (int32_t)id;
     }
-    // every thread has read cursor[tile] before the barrier that precedes the resolve:
-    // restore the all-zero invariant of the per-tile counters for the next frame
-    if (tid == 0) cursor[tile] = 0;
     CR_STAMP(3);
+#ifdef CRENDER_STAMPS
+    if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memtime();
+#endif
+    }   // work
+    // hand-off words of a heavy tile go back to zero once every wavefront has read them
+    if (quad >= 0) {
+        __syncthreads();
+        if (tid == 0) {
+            if (!helper) L.heavy_flag[tile] = 0;
+            else L.heavy_slots[b] = 0;
+        }
+    }
 }
 
 // ---- second implementation: global 64-bit atomics ---------------------------------
@@ -1302,15 +1896,19 @@ struct Layout {
     int64_t max_T;
     int64_t capacity;
     int64_t direct_cap;   // entries per tile of the direct bins, 0 = scene too large for them
-    size_t off_hdr, off_count, off_offs, off_trange, off_proj, off_entries, off_direct, total;
+    int hmax;             // helper triples of a raster launch (heavy tiles split in four), 0 = none
+    bool ordered;         // raster launches leave a dispatch order for the next one (build_order)
+    size_t count_stride;  // u32 words between the two parities of the per-tile counters
+    size_t off_hdr, off_count, off_hflag, off_hslots, off_hint, off_order, off_grouped, off_offs,
+           off_trange, off_proj, off_entries, off_direct, total;
 };
+constexpr int kMaxHeavyHelped = 128;   // +384 workgroups per raster launch (9 % at 1024 x 1024)
 
 // Direct bins are for small scenes (the README benchmark): one launch fewer than the
 // count / scan / fill path matters when a frame takes tens of microseconds.
 constexpr int64_t kDirectMaxTriangles = 1 << 16;
-constexpr int kDirectLdsMaxTiles = 4096;    // up to here: block-level LDS cursors (kBinDirect)
 constexpr int kDirectMaxTiles = 1 << 16;    // beyond: count / scan / fill
-constexpr int64_t kDirectBinBytes = 64ll << 20;   // per-tile capacity = this budget / tiles, <= 1024
+constexpr int64_t kDirectBinBytes = 512ll << 20;   // per-tile capacity = this budget / 48 B / tiles, <= 1024
 
 bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int tile, Layout &L)
 {
@@ -1336,19 +1934,31 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
     if (cap <= 0) cap = 4 * max_T + 4 * (int64_t)L.g.ntiles + 65536;
     if (cap > 0xFFFFFFF0ll) cap = 0xFFFFFFF0ll;
     L.capacity = cap;
+    L.direct_cap = 0;
+    if (max_T <= kDirectMaxTriangles && L.g.ntiles <= kDirectMaxTiles) {
+        L.direct_cap = kDirectBinBytes / (int64_t)sizeof(BinEntry) / L.g.ntiles;
+        if (L.direct_cap > 1024) L.direct_cap = 1024;
+    }
+    // heavy tiles are split on 16-pixel tiles with direct bins only (the small-frame regime,
+    // where a single tile's latency sets the end of the launch)
+    L.hmax = (L.ts == 16 && L.direct_cap >= 2 * kHeavyAt) ? (L.g.ntiles / 8 < kMaxHeavyHelped ? L.g.ntiles / 8 : kMaxHeavyHelped) : 0;
     size_t o = 0;
+    // [header | counters, parity 0 and 1 | heavy flags | heavy slots | order hints] are zeroed at creation
     L.off_hdr = o;     o = align_up(o + 64);
-    L.off_count = o;   o = align_up(o + sizeof(uint32_t) * (size_t)(L.g.ntiles + 1));
+    L.count_stride = align_up(sizeof(uint32_t) * (size_t)(L.g.ntiles + 1)) / sizeof(uint32_t);
+    L.off_count = o;   o = o + 2 * L.count_stride * sizeof(uint32_t);
+    L.off_hflag = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.g.ntiles);
+    L.off_hslots = o;  o = align_up(o + sizeof(uint32_t) * 3 * (size_t)(L.hmax > 0 ? L.hmax : 1));
+    // small frames are dispatched in the order the previous frame suggests (build_order)
+    L.ordered = L.ts == 16 && L.direct_cap > 0 && L.g.ntiles <= kOrderMaxTiles;
+    L.off_hint = o;    o = align_up(o + sizeof(uint32_t) * 8);                      // two headers of 4 words
+    L.off_order = o;   o = align_up(o + sizeof(uint32_t) * 2 * (size_t)(L.ordered ? L.g.ntiles : 0));
+    L.off_grouped = o; o = align_up(o + 2 * (size_t)(L.ordered ? L.g.ntiles : 0));
     L.off_offs = o;    o = align_up(o + sizeof(uint32_t) * (size_t)(L.g.ntiles + 1));
     L.off_trange = o;  o = align_up(o + sizeof(uint2) * (size_t)max_T);
     L.off_proj = o;    o = align_up(o + sizeof(float) * 9 * (size_t)max_T);
     L.off_entries = o; o = align_up(o + sizeof(uint32_t) * (size_t)cap);
-    L.direct_cap = 0;
-    if (max_T <= kDirectMaxTriangles && L.g.ntiles <= kDirectMaxTiles) {
-        L.direct_cap = kDirectBinBytes / 4 / L.g.ntiles;
-        if (L.direct_cap > 1024) L.direct_cap = 1024;
-    }
-    L.off_direct = o;  o = align_up(o + sizeof(uint32_t) * (size_t)L.g.ntiles * (size_t)L.direct_cap);
+    L.off_direct = o;  o = align_up(o + sizeof(BinEntry) * (size_t)L.g.ntiles * (size_t)L.direct_cap);
     L.total = o;
     return true;
 }
@@ -1365,11 +1975,24 @@ struct crender_plan {
     bool direct_ok = true;        // cleared once a frame overflowed the direct bins
     bool last_frame_direct = false;
     int64_t last_T = -1;          // triangle count of the last bin pass (crender_draw must match)
-    uint32_t *direct() const { return reinterpret_cast<uint32_t *>(ws + L.off_direct); }
+    // The per-tile counters exist twice.  Frame f bins into parity f & 1 and its raster pass
+    // zeroes the OTHER parity for frame f + 1, so no raster workgroup ever writes a counter that
+    // another workgroup of the same launch reads (the four workgroups of a heavy tile all read
+    // its count).  awaiting[p]: parity p was binned into and not zeroed since.
+    unsigned frame_no = 0;
+    int parity = 0;               // of the last bin pass
+    bool awaiting[2] = {false, false};
+    uint32_t *count(int par) const { return reinterpret_cast<uint32_t *>(ws + L.off_count) + (size_t)par * L.count_stride; }
+    uint32_t *hflag() const { return reinterpret_cast<uint32_t *>(ws + L.off_hflag); }
+    uint32_t *hslots() const { return reinterpret_cast<uint32_t *>(ws + L.off_hslots); }
+    int hint_par = 0;             // order / hint buffer the next raster launch reads (it writes the other)
+    uint32_t *hint(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_hint) + 4 * k; }
+    uint32_t *order(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_order) + (size_t)k * L.g.ntiles; }
+    unsigned char *grouped(int k) const { return ws + L.off_grouped + (size_t)k * L.g.ntiles; }
+    float4 *direct() const { return reinterpret_cast<float4 *>(ws + L.off_direct); }
     bool timing() const { return !events.empty() && (size_t)(timed_frames + 1) * 3 <= events.size(); }
     hipEvent_t ev(int k) const { return events[(size_t)timed_frames * 3 + k]; }
     uint32_t *hdr() const { return reinterpret_cast<uint32_t *>(ws + L.off_hdr); }
-    uint32_t *count() const { return reinterpret_cast<uint32_t *>(ws + L.off_count); }
     uint32_t *offs() const { return reinterpret_cast<uint32_t *>(ws + L.off_offs); }
     uint2 *trange() const { return reinterpret_cast<uint2 *>(ws + L.off_trange); }
     float *proj() const { return reinterpret_cast<float *>(ws + L.off_proj); }
@@ -1419,17 +2042,38 @@ int grid_for(size_t items, int cap)
 constexpr int kMaxLdsHistTiles = 16384;
 
 // Frame = bin pass (K1 + binning into the plan) + raster pass (K2 from the plan's bins).
+int dev_knobs()
+{
+#ifdef CRENDER_DEV_KNOBS
+    static const int dbg = std::getenv("CRENDER_DEBUG") ? std::atoi(std::getenv("CRENDER_DEBUG")) : 0;
+    return dbg;
+#else
+    return 0;
+#endif
+}
+
 template <int TS>
 int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const float *d_nrm, int64_t T,
                  const ProjConst &P, unsigned flags, hipStream_t s)
 {
     const Layout &L = plan->L;
     const Geom G = L.g;
-    static const int dbg = std::getenv("CRENDER_DEBUG") ? std::atoi(std::getenv("CRENDER_DEBUG")) : 0;
+    const int dbg = dev_knobs();
     const bool direct = L.direct_cap > 0 && plan->direct_ok && !(flags & CRENDER_NO_DIRECT_BINS) &&
                         !(dbg & 16);
     plan->last_frame_direct = direct;
     plan->last_T = T;
+    const int par = (int)(plan->frame_no++ & 1u);
+    plan->parity = par;
+    if (plan->awaiting[par]) {
+        // this parity was binned into and no raster pass has run since (two crender_prepare calls
+        // in a row): start over from the state crender_plan_create leaves
+        CR_HIP(hipMemsetAsync(plan->ws + L.off_count, 0, L.off_order - L.off_count, s));
+        CR_HIP(hipMemsetAsync(plan->hdr() + 2, 0, 5 * sizeof(uint32_t), s));   // heavy counters, hint_bad
+        plan->awaiting[0] = plan->awaiting[1] = false;
+    }
+    plan->awaiting[par] = true;
+    uint32_t *count = plan->count(par);
 
     // contiguous chunk of triangles per block, a multiple of the block size
     auto chunking = [T](int64_t max_blocks, int64_t &nblk, int64_t &chunk) {
@@ -1442,14 +2086,32 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
     // block-private LDS histograms pay off when a block's chunk is dense in tiles; a small
     // scene on a large tile grid would only zero and flush mostly empty histograms
     const bool lds_hist = G.ntiles <= 4096 || (G.ntiles <= kMaxLdsHistTiles && T >= 16 * (int64_t)G.ntiles);
-    if (T > 0) {
+    if (T > 0 && direct) {
+        // direct bins: one wavefront per 64 triangles
+        HeavyReg hv;
+        if (L.hmax > 0 && !(dbg & 2048)) {
+            hv.ctr = plan->hdr() + 2 + par; hv.flag = plan->hflag(); hv.slots = plan->hslots();
+            hv.hmax = (uint32_t)L.hmax;
+        }
+        if (L.ordered) {
+            hv.grouped = plan->grouped(plan->hint_par);    // of the order this frame's raster pass reads
+            hv.hint_bad = plan->hdr() + 5 + par;
+        }
+        const unsigned nwg = (unsigned)((T + kWave - 1) / kWave);
+        if (project)
+            hipLaunchKernelGGL((k_setup_wave<TS, true>), dim3(nwg), dim3(kWave), 0, s, d_tri, d_nrm,
+                               plan->proj(), count, plan->direct(), (uint32_t)L.direct_cap, plan->hdr(),
+                               hv, T, P, G);
+        else
+            hipLaunchKernelGGL((k_setup_wave<TS, false>), dim3(nwg), dim3(kWave), 0, s, d_tri, d_nrm,
+                               plan->proj(), count, plan->direct(), (uint32_t)L.direct_cap, plan->hdr(),
+                               hv, T, P, G);
+        CR_LAUNCH_CHECK("k_setup_wave");
+    } else if (T > 0) {
         int64_t nblk, chunk;
         chunking(2048, nblk, chunk);
-        const int bin = direct ? (G.ntiles <= kDirectLdsMaxTiles ? kBinDirect : kBinDirectGlobal)
-                               : (lds_hist ? kBinCountLds : kBinCountGlobal);
-        const size_t hist_bytes = bin == kBinDirect ? sizeof(uint32_t) * (size_t)((G.ntiles + 3) & ~3)
-                                : bin == kBinCountLds ? sizeof(uint32_t) * (size_t)((((G.ntiles + 1) >> 1) + 3) & ~3) : 0;
-        while (bin == kBinCountLds && chunk > 65280) {   // 16-bit block-local counters
+        const size_t hist_bytes = lds_hist ? sizeof(uint32_t) * (size_t)((((G.ntiles + 1) >> 1) + 3) & ~3) : 0;
+        while (lds_hist && chunk > 65280) {   // 16-bit block-local counters
             nblk *= 2;
             chunk = ((T + nblk - 1) / nblk + kThreads - 1) / kThreads * kThreads;
             nblk = (T + chunk - 1) / chunk;
@@ -1457,24 +2119,19 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
         const size_t setup_lds = hist_bytes + sizeof(float) * kThreads * 9 * 2;
 #define CR_SETUP(PROJ, BIN)                                                                          \
     hipLaunchKernelGGL((k_setup<TS, PROJ, BIN>), dim3((unsigned)nblk), dim3(kThreads), setup_lds, s, \
-                       d_tri, d_nrm, plan->proj(), plan->trange(), plan->count(), plan->direct(),    \
-                       (uint32_t)L.direct_cap, plan->hdr(), T, chunk, P, G)
+                       d_tri, d_nrm, plan->proj(), plan->trange(), count, T, chunk, P, G)
         if (project) {
-            if (bin == kBinDirect) CR_SETUP(true, kBinDirect);
-            else if (bin == kBinDirectGlobal) CR_SETUP(true, kBinDirectGlobal);
-            else if (bin == kBinCountLds) CR_SETUP(true, kBinCountLds);
+            if (lds_hist) CR_SETUP(true, kBinCountLds);
             else CR_SETUP(true, kBinCountGlobal);
         } else {
-            if (bin == kBinDirect) CR_SETUP(false, kBinDirect);
-            else if (bin == kBinDirectGlobal) CR_SETUP(false, kBinDirectGlobal);
-            else if (bin == kBinCountLds) CR_SETUP(false, kBinCountLds);
+            if (lds_hist) CR_SETUP(false, kBinCountLds);
             else CR_SETUP(false, kBinCountGlobal);
         }
 #undef CR_SETUP
         CR_LAUNCH_CHECK("k_setup");
     }
     if (!direct) {
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, plan->count(), plan->offs(), plan->hdr(),
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, count, plan->offs(), plan->hdr(),
                            G.ntiles);
         CR_LAUNCH_CHECK("k_scan");
         if (T > 0) {
@@ -1489,11 +2146,11 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
             }
             if (lds_hist)
                 hipLaunchKernelGGL((k_fill<true>), dim3((unsigned)nblk), dim3(kThreads), lds, s,
-                                   plan->trange(), plan->offs(), plan->count(), plan->entries(),
+                                   plan->trange(), plan->offs(), count, plan->entries(),
                                    (uint32_t)L.capacity, T, chunk, G);
             else
                 hipLaunchKernelGGL((k_fill<false>), dim3((unsigned)nblk), dim3(kThreads), 0, s,
-                                   plan->trange(), plan->offs(), plan->count(), plan->entries(),
+                                   plan->trange(), plan->offs(), count, plan->entries(),
                                    (uint32_t)L.capacity, T, chunk, G);
             CR_LAUNCH_CHECK("k_fill");
         }
@@ -1508,20 +2165,44 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
 {
     const Layout &L = plan->L;
     const Geom G = L.g;
-    static const int dbg = std::getenv("CRENDER_DEBUG") ? std::atoi(std::getenv("CRENDER_DEBUG")) : 0;
+    const int dbg = dev_knobs();
     const bool direct = plan->last_frame_direct;
-    const uint32_t *offs = direct ? nullptr : plan->offs();
-    const uint32_t *list = direct ? plan->direct() : plan->entries();
-    const uint32_t cap = direct ? (uint32_t)L.direct_cap : (uint32_t)L.capacity;
+    const int par = plan->parity;
+    TileLists tl;
+    tl.offs = direct ? nullptr : plan->offs();
+    tl.count = plan->count(par);
+    tl.count_next = plan->count(par ^ 1);
+    tl.entries = plan->entries();
+    tl.bins = plan->direct();
+    tl.capacity = direct ? (uint32_t)L.direct_cap : (uint32_t)L.capacity;
+    tl.T = (uint32_t)plan->last_T;
+    const bool split = direct && L.hmax > 0 && !(dbg & 2048);
+    tl.heavy_flag = split ? plan->hflag() : nullptr;
+    tl.heavy_slots = split ? plan->hslots() : nullptr;
+    tl.heavy_ctr_next = plan->hdr() + 2 + (par ^ 1);
+    tl.nhelp = split ? 3 * L.hmax : 0;
+    // ordered launches: read the order the previous launch left, leave one for the next
+    const bool ordered = direct && L.ordered && !(dbg & 1024);
+    const int hp = plan->hint_par;
+    tl.order = ordered ? plan->order(hp) : nullptr;
+    tl.hint = plan->hint(hp);
+    tl.order_next = ordered ? plan->order(hp ^ 1) : nullptr;
+    tl.hint_next = plan->hint(hp ^ 1);
+    tl.grouped_next = ordered ? plan->grouped(hp ^ 1) : nullptr;
+    tl.hint_bad = plan->hdr() + 5 + par;
+    tl.hint_bad_next = plan->hdr() + 5 + (par ^ 1);
+    if (ordered) plan->hint_par = hp ^ 1;
+    const uintptr_t any = (uintptr_t)d_z | (uintptr_t)d_color | (uintptr_t)d_normal | (uintptr_t)d_winner;
+    tl.vec_clear = (any & 15u) == 0 && (G.W & 3) == 0;
+    const unsigned grid = (unsigned)(G.ntiles + tl.nhelp + (ordered ? 1 : 0));
     if (flags & CRENDER_FUSED_CLEAR)
-        hipLaunchKernelGGL((k_raster<TS, true>), dim3((unsigned)G.ntiles), dim3(kThreads), 0, s, proj,
-                           d_col, d_nrm, offs, plan->count(), list, cap, d_z, d_color, d_normal,
-                           d_winner, G, dbg);
+        hipLaunchKernelGGL((k_raster<TS, true>), dim3(grid), dim3(kThreads), 0, s, proj, d_col, d_nrm, tl,
+                           d_z, d_color, d_normal, d_winner, G, dbg);
     else
-        hipLaunchKernelGGL((k_raster<TS, false>), dim3((unsigned)G.ntiles), dim3(kThreads), 0, s, proj,
-                           d_col, d_nrm, offs, plan->count(), list, cap, d_z, d_color, d_normal,
-                           d_winner, G, dbg);
+        hipLaunchKernelGGL((k_raster<TS, false>), dim3(grid), dim3(kThreads), 0, s, proj, d_col, d_nrm, tl,
+                           d_z, d_color, d_normal, d_winner, G, dbg);
     CR_LAUNCH_CHECK("k_raster");
+    plan->awaiting[par ^ 1] = false;     // zeroed by this launch
     return CRENDER_OK;
 }
 
@@ -1723,7 +2404,7 @@ int crender_plan_timing_end(crender_plan *plan, void *stream, int *frames, doubl
 int crender_plan_last_bin_usage(crender_plan *plan, void *stream, int64_t *needed, int64_t *capacity)
 {
     if (!plan) return fail(CRENDER_EINVAL, "null plan");
-    uint32_t h[2] = {0, 0};
+    uint32_t h[5] = {0, 0, 0, 0, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     CR_HIP(hipMemcpyAsync(h, plan->hdr(), sizeof h, hipMemcpyDeviceToHost, s));
     CR_HIP(hipStreamSynchronize(s));
@@ -1737,7 +2418,7 @@ int crender_plan_last_bin_usage(crender_plan *plan, void *stream, int64_t *neede
         if (capacity) *capacity = cap;
         return CRENDER_OK;
     }
-    if (needed) *needed = h[0];
+    if (needed) *needed = (int64_t)(((unsigned long long)h[4] << 32) | h[0]);
     if (capacity) *capacity = plan->L.capacity;
     return CRENDER_OK;
 }

@@ -56,17 +56,26 @@ class StripRenderer:
         from .pixel_buffer_filler import AdvancedPixelBufferFiller
         self.rank, self.world, self.group = rank, world, group
         self.h = h
+        y0, y1 = strip_rows(h, world, rank)
+        self.empty = y0 >= y1        # more ranks than rows: this rank owns nothing, it only gathers
         self.filler = AdvancedPixelBufferFiller(h, w, fov=fov, z_near=z_near, z_far=z_far,
                                                 device=device, tile=tile,
-                                                row_strip=strip_rows(h, world, rank))
+                                                row_strip=None if self.empty else (y0, y1))
 
     def set_model_arrays(self, tri, col, nrm):
+        """Upload the (replicated) model and render a first frame of the strip; synchronises, so
+        that a bin-list overflow is found and repaired BEFORE any strip is gathered."""
+        if self.empty:
+            return
         self.filler.render_arrays(tri, col, nrm, clear=True)
+        self.filler.synchronize()
 
     def render_frame(self, gather=True):
         f = self.filler
-        if f.y1 > f.y0:
+        if not self.empty:
             f.render_frame()
         if gather:
+            if not self.empty:
+                f.join()         # the collective runs on the current stream
             all_gather_strips([f.z_buffer, f.color_buffer, f.normals_buffer], self.h, self.rank,
                               self.world, self.group)

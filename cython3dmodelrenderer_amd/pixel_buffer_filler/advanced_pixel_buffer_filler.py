@@ -15,9 +15,14 @@ or a GPU the constructor raises.
 Behaviour kept from the reference
   * buffers persist across ``render_model`` calls and are never cleared, so successive
     renders composite (``Renderer.reset_buffers`` is a no-op there, renderer.py:51-52);
-  * getters hand out writable numpy arrays that stay valid and that callers may change
-    in place (GuroIllumination does, guro_illumination.py:27); such changes are carried
-    back to the device before the next render;
+  * getters hand out writable numpy arrays that stay valid, that callers may change in place
+    (GuroIllumination does, guro_illumination.py:27) and that show every later render, like the
+    reference's views of its own buffers (.pyx:246-253): in-place changes are carried to the
+    device before the next render, and every array handed out so far is refreshed at the end of
+    each ``render_model``;
+  * the three model arrays are read afresh on every ``render_model`` call, as the reference's
+    per-call ``.copy()`` does (.pyx:94-96): an in-place edit of ``model._vertices_by_triangles``
+    is honoured (``cache_inputs=True`` restores the upload cache keyed by array identity);
   * ``model._colors_by_triangles is None`` raises AttributeError, float64 arrays raise
     ValueError (.pyx:94-96 binds ``float[:, :, :]`` after ``.copy()``);
   * ``n_threads`` is accepted and ignored.
@@ -78,12 +83,13 @@ class _FramePipeline:
         self.depth = int(depth)
         self.plans, self.workspaces = [], []
         for _ in range(self.depth):
+            cap = max(filler._bin_request, filler._bin_floor)
             nbytes = self.lib.crender_plan_workspace_bytes(filler.h, filler.w, filler.y0, filler.y1,
-                                                           max(int(T), 1), filler._bin_request, filler.tile)
+                                                           max(int(T), 1), cap, filler.tile)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             plan = C.c_void_p()
             _capi.check(self.lib.crender_plan_create(C.byref(plan), filler.h, filler.w, filler.y0,
-                                                     filler.y1, max(int(T), 1), filler._bin_request,
+                                                     filler.y1, max(int(T), 1), cap,
                                                      filler.tile, ws.data_ptr(), nbytes, filler._stream()),
                         "crender_plan_create")
             self.plans.append(plan)
@@ -146,21 +152,26 @@ class _FramePipeline:
         self.pending = False
         self.k = 0                 # the library restarts its frame parity at a join
 
-    def overflowed(self, filler):
-        """Synchronising check of every plan's bin lists."""
+    def overflow(self, filler):
+        """Synchronising check of every plan's bin lists: None, or (direct bins?, entries needed)
+        of the worst plan."""
         self.join(filler)
+        worst = None
         for plan in self.plans:
             need, cap = C.c_int64(), C.c_int64()
             _capi.check(self.lib.crender_plan_last_bin_usage(plan, filler._stream(), C.byref(need),
                                                              C.byref(cap)), "crender_plan_last_bin_usage")
-            if need.value > cap.value:
-                return True
-        return False
+            if need.value > cap.value and (worst is None or need.value > worst[1]):
+                worst = (bool(self.lib.crender_plan_last_frame_direct(plan)), need.value)
+        return worst
+
+    def overflowed(self, filler):
+        return self.overflow(filler) is not None
 
 
 class AdvancedPixelBufferFiller:
     def __init__(self, h, w, fov=90.0, z_near=0.1, z_far=1000.0, n_threads=1, *,
-                 device=None, tile=0, row_strip=None, track_winner=False, cache_inputs=True,
+                 device=None, tile=0, row_strip=None, track_winner=False, cache_inputs=False,
                  bin_capacity=0, direct_bins=True, pipeline=False, pipeline_depth=None):
         self._lib = _capi.load()                      # raises if the HIP library is missing
         if not torch.cuda.is_available():
@@ -173,6 +184,7 @@ class AdvancedPixelBufferFiller:
         self.y0, self.y1 = (0, self.h) if row_strip is None else (int(row_strip[0]), int(row_strip[1]))
         self.cache_inputs = cache_inputs
         self._bin_request = int(bin_capacity)   # 0 = let the library size the bin lists
+        self._bin_floor = 0                     # what an overflow taught us this scene needs
 
         P = (C.c_float * 16)()
         _capi.check(self._lib.crender_projection_matrix(self.fov, self.z_near, self.z_far,
@@ -198,6 +210,7 @@ class AdvancedPixelBufferFiller:
         self._host = {}                # name -> numpy mirror handed out by a getter
         self._host_fresh = False       # mirrors equal the device buffers
         self._host_exposed = False     # a mirror was handed out and may have been edited
+        self._unverified = False       # a frame was launched whose bin lists have not been checked
         self._pipeline = bool(pipeline)  # render_frame(): overlap consecutive frames (see _FramePipeline)
         if not pipeline_depth:
             # measured on MI355X (scripts/ab_depth.sh): three frames in flight, or four for small
@@ -211,6 +224,7 @@ class AdvancedPixelBufferFiller:
             pipeline_depth = 4 if (self.h * self.w <= 1024 * 1024 and queues >= 6) else 3
         self._pipeline_depth = max(2, min(8, int(pipeline_depth)))
         self._pipe = None
+        self._checking = False
 
     # ------------------------------------------------------------------ plumbing --
     def __del__(self):
@@ -232,6 +246,9 @@ class AdvancedPixelBufferFiller:
         if self._plan and T <= self._plan_max_T and capacity <= self._plan_capacity:
             return
         if self._plan:
+            if self._unverified and not self._checking:
+                self._check_bins()         # (may replace the plan itself: start over)
+                return self._ensure_plan(T, capacity)
             torch.cuda.current_stream(self.device).synchronize()
             self._lib.crender_plan_destroy(self._plan)
             self._plan = C.c_void_p()
@@ -274,8 +291,16 @@ class AdvancedPixelBufferFiller:
     def _win_ptr(self):
         return self.winner_buffer.data_ptr() if self.winner_buffer is not None else None
 
-    def _launch(self, flags):
+    def _launch(self, flags, inputs=None):
         self._join_pipe()
+        if self._unverified and not self._checking and not (flags & _capi.FUSED_CLEAR):
+            # This frame composites on top of the previous one.  If that one overflowed its bin
+            # lists it has to be redone NOW, from its own inputs: afterwards the buffers would
+            # hold this frame too, and replaying the earlier model on top of a later one is not
+            # the reference's result (the later call must win equal depths).
+            self._check_bins()
+        if inputs is not None:
+            self._inputs = inputs
         tri, col, nrm = self._inputs
         T = tri.shape[0]
         self._ensure_plan(T)
@@ -286,17 +311,34 @@ class AdvancedPixelBufferFiller:
                 self._win_ptr(), flags | self._extra_flags, self._stream()), "crender_render_model")
         self._last_flags = flags
         self._host_fresh = False
+        self._unverified = True
 
     def _check_bins(self):
         """Synchronise; if the last frame overflowed its bin lists, grow them and redo it.
         Re-rendering is exact: the result is a per-pixel minimum over the prior value and
         all fragments, so fragments that already landed change nothing."""
+        self._checking = True
+        try:
+            self._check_bins_locked()
+        finally:
+            self._checking = False
+        self._unverified = False
+
+    def _check_bins_locked(self):
         if self._pipe is not None and self._pipe.n > 0:
-            if self._pipe.overflowed(self):
-                # rare: leave pipelining for good and redo the frame on the plain path
+            need = self._pipe.overflow(self)
+            if need:
+                # rare: the swap chain's bin lists were too small for this scene.  Remember the
+                # larger size (the chain is rebuilt with it at the next pipelined frame) and redo
+                # the frame on the plain path.
+                direct, entries = need
+                if direct:
+                    self._extra_flags |= _capi.NO_DIRECT_BINS
+                else:
+                    self._bin_floor = max(self._bin_floor, int(entries * 1.25) + 1024)
+                torch.cuda.synchronize(self.device)
                 self._pipe.close()
                 self._pipe = None
-                self._pipeline = False
                 self._launch(_capi.FUSED_CLEAR)
             else:
                 self._pipe.n = 0
@@ -311,9 +353,10 @@ class AdvancedPixelBufferFiller:
                 # this scene does not fit the small-scene direct bins: general path from now on
                 self._extra_flags |= _capi.NO_DIRECT_BINS
             else:
-                self._ensure_plan(self._inputs[0].shape[0], capacity=int(need.value * 1.25) + 1024)
+                self._bin_floor = max(self._bin_floor, int(need.value * 1.25) + 1024)
+                self._ensure_plan(self._inputs[0].shape[0], capacity=self._bin_floor)
             self._launch(self._last_flags)
-            self._check_bins()
+            self._check_bins_locked()
 
     # ------------------------------------------------------------- reference API --
     def get_size(self):
@@ -324,15 +367,21 @@ class AdvancedPixelBufferFiller:
         src = (model._vertices_by_triangles, model._colors_by_triangles, model._normals_by_triangles)
         key = tuple((id(a), getattr(a, "shape", None)) for a in src)
         if refresh or not self.cache_inputs or key != self._input_key:
-            self._inputs = (_as_device_f32(src[0], "model._vertices_by_triangles", self.device),
-                            _as_device_f32(src[1], "model._colors_by_triangles", self.device),
-                            _as_device_f32(src[2], "model._normals_by_triangles", self.device))
-            if not (self._inputs[0].shape == self._inputs[1].shape == self._inputs[2].shape):
+            inputs = (_as_device_f32(src[0], "model._vertices_by_triangles", self.device),
+                      _as_device_f32(src[1], "model._colors_by_triangles", self.device),
+                      _as_device_f32(src[2], "model._normals_by_triangles", self.device))
+            if not (inputs[0].shape == inputs[1].shape == inputs[2].shape):
                 raise ValueError("vertex, colour and normal arrays must have the same shape")
-            self._input_key = key
+            self._input_key = key if self.cache_inputs else None
             self._input_refs = src         # keep ids alive while the key is cached
+        else:
+            inputs = None
         self._push_host_edits()
-        self._launch(0)
+        self._launch(0, inputs)            # (a pending overflow check needs the OLD inputs first)
+        if self._host:
+            # arrays handed out earlier are views of the reference's own buffers there: they show
+            # this render too
+            self._refresh_mirrors()
 
     # north_star wording; the reference's method is render_model
     render = render_model
@@ -350,14 +399,14 @@ class AdvancedPixelBufferFiller:
     def render_arrays(self, tri, col, nrm, clear=False):
         """``render_model`` on explicit [T,3,3] float32 arrays (numpy or torch, any device).
         ``clear=True`` renders into freshly initialised buffers in the same pass."""
-        self._inputs = (_as_device_f32(tri, "tri", self.device), _as_device_f32(col, "col", self.device),
-                        _as_device_f32(nrm, "nrm", self.device))
+        inputs = (_as_device_f32(tri, "tri", self.device), _as_device_f32(col, "col", self.device),
+                  _as_device_f32(nrm, "nrm", self.device))
         self._input_key = None
         if clear:
             self._host_exposed = False
         else:
             self._push_host_edits()
-        self._launch(_capi.FUSED_CLEAR if clear else 0)
+        self._launch(_capi.FUSED_CLEAR if clear else 0, inputs)
 
     def render_frame(self, pipelined=None):
         """One benchmark frame: clear + project + rasterize the resident model
@@ -448,14 +497,17 @@ class AdvancedPixelBufferFiller:
         self._check_bins()
         return self.winner_buffer
 
+    def _refresh_mirrors(self):
+        self._check_bins()
+        for n, b in (("z", self.z_buffer), ("color", self.color_buffer),
+                     ("normals", self.normals_buffer)):
+            if n in self._host:
+                self._host[n][...] = b.cpu().numpy()
+        self._host_fresh = True
+
     def _mirror(self, name, buf):
         if not self._host_fresh:
-            self._check_bins()
-            for n, b in (("z", self.z_buffer), ("color", self.color_buffer),
-                         ("normals", self.normals_buffer)):
-                if n in self._host:
-                    self._host[n][...] = b.cpu().numpy()
-            self._host_fresh = True
+            self._refresh_mirrors()
         if name not in self._host:
             self._host[name] = buf.cpu().numpy()
         self._host_exposed = True

@@ -15,19 +15,27 @@ from cython3dmodelrenderer_amd import _capi, scenes
 from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
 wl = sys.argv[1] if len(sys.argv) > 1 else "trex1024"; tile = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 tri, col, nrm, (H, W), fov = scenes.scene(wl)
+if os.environ.get("STAMPS_TRI"):       # keep a slice of the model: "first:count"
+    a, b = (int(v) for v in os.environ["STAMPS_TRI"].split(":"))
+    tri, col, nrm = tri[a:a + b], col[a:a + b], nrm[a:a + b]
 L = _capi.load()
 f = AdvancedPixelBufferFiller(H, W, fov=fov, tile=tile)
 f.render_arrays(tri, col, nrm, clear=True); f.synchronize()
 ts = tile or (16 if H * W <= 1024 * 1024 else 32)   # pick_tile() of crender_hip.hip
 nt = ((W + ts - 1) // ts) * ((H + ts - 1) // ts)
-buf = torch.zeros(nt * 8, dtype=torch.int64, device="cuda:0")
+nhelp = 3 * min(nt // 8, 128) if ts == 16 else 0      # make_layout(): helper workgroups lead the grid
+nwg = nt + nhelp
+buf = torch.zeros(nwg * 16, dtype=torch.int64, device="cuda:0")
 L.crender_debug_set_stamps.argtypes = [C.c_void_p]; L.crender_debug_set_stamps.restype = C.c_int
 for _ in range(3): f.render_frame()
 f.synchronize()
 assert L.crender_debug_set_stamps(buf.data_ptr()) == 0
 f.render_frame(); f.synchronize()
 L.crender_debug_set_stamps(None)
-s = buf.cpu().numpy().reshape(nt, 8).astype(np.int64)
+s = buf.cpu().numpy().reshape(nwg, 16).astype(np.int64)
+ran = s[:, 0] != 0
+print(f"workgroups {nwg} ({nhelp} helper slots, {int(ran[:nhelp].sum())} used); quadrant workgroups {int((s[:, 9] > 0).sum())}")
+s = s[ran]; nt = len(s)
 # stamps are s_memrealtime ticks (100 MHz, device-wide); shown in ns since the first tile's start
 for k in (0, 1, 2, 3, 5, 6):
     s[:, k] *= 10
@@ -35,6 +43,10 @@ base = np.full(nt, s[:, 0].min(), np.int64)
 empty = s[:, 1] == 0            # empty tiles take the fast path and only stamp start / end
 s[empty, 1] = s[empty, 0]; s[empty, 2] = s[empty, 0]
 start, ready, swept, end, n = s[:, 0] - base, s[:, 1] - base, s[:, 2] - base, s[:, 3] - base, s[:, 4]
+wk = s[:, 11] != 0
+if wk.any():
+    mhz = (s[wk, 11] - s[wk, 10]) / np.maximum(s[wk, 3] - s[wk, 0], 1) * 1000.0
+    print("shader clock of working workgroups (s_memtime / s_memrealtime): p10 %.0f p50 %.0f p90 %.0f MHz" % tuple(np.percentile(mhz, [10, 50, 90])))
 print("XCDs:", len(set(s[:, 7].tolist())))
 print(f"{wl} tile={ts} tiles={nt} kernel span {end.max()} ns")
 print("start (since its XCD's first tile): p50 %d p90 %d max %d | active tiles p50 %d p90 %d max %d" % (

@@ -27,9 +27,10 @@ L.crender_debug_set_setup_stamps(None)
 s = buf.cpu().numpy().reshape(nb, 8).astype(np.int64) * 10      # ns
 s = s[s[:, 0] > 0]
 t0 = s[:, 0].min()
-names = ["start", "inputs staged", "ranges + tile box", "pass A (LDS counts)", "pass B (global atomics)", "batch done"]
+names = ["start", "inputs staged", "projected, ranges known", "pass A (LDS counts)", "pass B (global atomics)", "entries issued"]
 print(f"{wl}: {len(s)} workgroups; ns since the first workgroup's start (p50 / max)")
 for k, nm in enumerate(names):
-    v = s[:, k] - t0
-    if (s[:, k] > 0).all():
-        print(f"  {nm:28s} p50 {np.percentile(v, 50):7.0f}  max {v.max():7d}")
+    ok = s[:, k] > 0
+    if ok.any():
+        v = s[ok, k] - t0
+        print(f"  {nm:28s} p50 {np.percentile(v, 50):7.0f}  max {v.max():7d}  ({int(ok.sum())} workgroups)")

@@ -790,3 +790,46 @@ def test_synthetic_small_triangles_at_4096(hip, oracle):
     twice = gpu_frame(hip, tri, col, nrm, 4096, 4096, mode="fused", prior=got[:3])
     for a, b, what in zip(got[:3], twice[:3], ("z", "colour", "normal")):
         assert_bit_equal(a, b, f"idempotence: {what}")
+
+
+@pytest.mark.parametrize("clear", [True, False])
+def test_dispatch_order_hint_never_changes_pixels(hip, oracle, clear):
+    """On 16-pixel tiles each raster launch leaves a dispatch order for the next launch on the same
+    plan (covered tiles first, empty tiles cleared in groups without a look at their lists).  The
+    order is a hint about speed only: frames of the same model, of another model (stale order), of
+    the model moved by a few pixels and by half a frame, and of no triangles at all, rendered one
+    after another on ONE plan, must each equal the oracle bit for bit."""
+    H = W = 512
+    tri, col, nrm = scene("trex_inputs.npz")
+    ctri, ccol, cnrm = scene("cube_inputs.npz")
+    rng = np.random.default_rng(5)
+    stri, scol, snrm = random_soup(rng, 400, H, size_px=(2, 30))
+
+    def moved(dx, dy):
+        t = tri.copy()
+        t[..., 0] += np.float32(dx) * t[..., 2]
+        t[..., 1] += np.float32(dy) * t[..., 2]
+        return t
+
+    e = np.zeros((0, 3, 3), np.float32)
+    frames = [(tri, col, nrm), (tri, col, nrm), (tri, col, nrm), (moved(0.01, 0.0), col, nrm),
+              (moved(0.02, 0.01), col, nrm), (ctri, ccol, cnrm), (ctri, ccol, cnrm), (tri, col, nrm),
+              (e, e, e), (tri, col, nrm), (moved(0.4, -0.3), col, nrm), (stri, scol, snrm),
+              (stri, scol, snrm), (tri, col, nrm)]
+    P = hip.projection_matrix(45.0, 0.1, 1000.0, H, W)
+    plan = hip.Plan(H, W, max(len(tri), len(stri)), tile=16)
+    fb = hip.FrameBuffers(H, W)
+    ref = oracle.OracleFiller(H, W, fov=45.0)
+    for k, (t, c, n) in enumerate(frames):
+        if clear:
+            ref.clear()
+        ref.render_arrays(t, c, n)
+        if len(t):
+            hip.render_model(plan, _dev(t), _dev(c), _dev(n), P, fb, clear=clear)
+        else:
+            import torch
+            z = torch.zeros((0, 3, 3), dtype=torch.float32, device="cuda:0")
+            hip.render_model(plan, z, z, z, P, fb, clear=clear)
+        need, cap = plan.bin_usage()
+        assert need <= cap and plan.last_frame_direct()
+        compare(tuple(fb.numpy()) + (None,), ref, f"frame {k} on one plan (clear={clear})")
