@@ -14,6 +14,7 @@ ABI_VERSION = 1
 OK, EINVAL, EHIP, ENOMEM = 0, 1, 2, 3
 FUSED_CLEAR = 1
 NO_DIRECT_BINS = 2
+OVERLAPPED_FRAMES = 4
 
 _vp, _i32, _i64, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint, C.c_size_t
 _f32p = C.POINTER(C.c_float)

@@ -375,15 +375,17 @@ static_assert(sizeof(BinEntry) == 48, "three 16-byte pieces");
 constexpr int kEntryPieces = sizeof(BinEntry) / 16;
 
 // ---- heavy tiles (direct bins, 16-pixel tiles) ---------------------------------------------
-// A tile whose list reaches kHeavyAt entries is rasterized by four workgroups, one per 8x8
-// quadrant, instead of one: on T-Rex 1024^2 the 36 tiles with >= 64 records set the end of the
-// raster launch (in-kernel timeline, profiles/r02).  The append that crosses kHeavyAt registers
+// A tile whose list reaches kHeavyAt entries is rasterized by two workgroups (upper and lower
+// half), from kQuadAt entries on by four (one per 8x8 quadrant), instead of one: a workgroup's
+// time grows with the trips its sweep takes and on T-Rex 1024^2 the 105 tiles with >= 32 records
+// set the end of the raster launch, 4 us after the median tile (in-kernel timeline, profiles/r02).  The append that crosses kHeavyAt registers
 // the tile: it draws an index from the frame's counter (hdr[2 + parity]) and, if one of the
 // launch's `hmax` helper triples is still free, raises the tile's flag and writes tile + 1 into
-// the triple's three slot words.  k_raster's helper workgroups take quadrants 1..3; the tile's
-// own workgroup takes quadrant 0 when the flag is up.  Flag and slots are reset by their
+// the triple's three slot words.  k_raster's helper workgroups take parts 1..3 (part 1 alone when
+// the list stays below kQuadAt); the tile's own workgroup takes part 0 when the flag is up.  Flag and slots are reset by their
 // readers, the counter of the NEXT frame by k_raster.
-constexpr uint32_t kHeavyAt = 64;
+constexpr uint32_t kHeavyAt = 32;     // lists from here on are split in two halves (16 x 8 pixels),
+constexpr uint32_t kQuadAt = 64;      // from here on in four quadrants (8 x 8)
 struct HeavyReg {
     uint32_t *ctr = nullptr;     // this frame's counter; null = no splitting
     uint32_t *flag = nullptr;    // [ntiles]
@@ -1253,10 +1255,10 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
         b -= 1;
     }
     const bool helper = b < L.nhelp;
-    int quad = -1;               // -1 = the whole tile, 0..3 = one 8x8 quadrant of a heavy tile
+    int quad = -1;               // -1 = the whole tile, 0..3 = one part of a heavy tile (half or quadrant)
     int tile;
     if (helper) {
-        // quadrant 1..3 of the heavy tile registered in this workgroup's slot, if any
+        // part 1..3 of the heavy tile registered in this workgroup's slot, if any
         const uint32_t v = L.heavy_slots[b];
         if (v == 0) return;                        // (same word for every thread: uniform)
         tile = (int)v - 1;
@@ -1358,10 +1360,20 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
         // the other parity's counter of this tile: zero for the next frame
         if (tid == 0) L.count_next[tile] = 0;
     }
+    int rw = TS;                 // width of this workgroup's rectangle in the key plane's terms
     if (quad >= 0) {
         constexpr int HS = TS / 2;
-        X0 += (quad & 1) * HS; Y0 += (quad >> 1) * HS;
-        if (X1 > X0 + HS) X1 = X0 + HS;
+        if (end - beg >= kQuadAt) {             // four quadrants
+            X0 += (quad & 1) * HS; Y0 += (quad >> 1) * HS;
+            if (X1 > X0 + HS) X1 = X0 + HS;
+            rw = HS;
+        } else {                                // two halves; parts 2 and 3 have nothing to do
+            if (quad >= 2) {
+                if (tid == 0) L.heavy_slots[b] = 0;
+                return;
+            }
+            Y0 += quad * HS;
+        }
         if (Y1 > Y0 + HS) Y1 = Y0 + HS;
         if (X1 < X0) X1 = X0;
         if (Y1 < Y0) Y1 = Y0;
@@ -1702,10 +1714,10 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
 
     CR_STAMP(2);
     // resolve: every pixel of the rectangle is written at most once (exactly once if CLEAR).
-    // A quadrant's 64 pixels are taken by the first wavefront in rows of 8.
-    const int npx = quad >= 0 ? (TS / 2) * (TS / 2) : TS * TS;
+    // A part's pixels are taken by the first wavefronts in rows of its own width.
+    const int npx = quad >= 0 ? rw * (TS / 2) : TS * TS;
     for (int p0 = tid; p0 < npx; p0 += kThreads) {
-        const int dx = quad >= 0 ? p0 % (TS / 2) : p0 % TS, dy = quad >= 0 ? p0 / (TS / 2) : p0 / TS;
+        const int dy = rw == TS ? p0 / TS : p0 / (TS / 2), dx = p0 - dy * rw;
         const int x = X0 + dx, y = Y0 + dy;
         if (x >= X1 || y >= Y1) continue;
         const int p = dy * TS + dx;
@@ -1986,6 +1998,8 @@ struct crender_plan {
     uint32_t *hflag() const { return reinterpret_cast<uint32_t *>(ws + L.off_hflag); }
     uint32_t *hslots() const { return reinterpret_cast<uint32_t *>(ws + L.off_hslots); }
     int hint_par = 0;             // order / hint buffer the next raster launch reads (it writes the other)
+    bool frame_lone = true;       // the last bin pass belonged to a frame rendered for latency (no
+                                  // CRENDER_OVERLAPPED_FRAMES): ordered dispatch and split heavy tiles
     uint32_t *hint(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_hint) + 4 * k; }
     uint32_t *order(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_order) + (size_t)k * L.g.ntiles; }
     unsigned char *grouped(int k) const { return ws + L.off_grouped + (size_t)k * L.g.ntiles; }
@@ -2065,6 +2079,7 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
     plan->last_T = T;
     const int par = (int)(plan->frame_no++ & 1u);
     plan->parity = par;
+    plan->frame_lone = !(flags & CRENDER_OVERLAPPED_FRAMES);
     if (plan->awaiting[par]) {
         // this parity was binned into and no raster pass has run since (two crender_prepare calls
         // in a row): start over from the state crender_plan_create leaves
@@ -2089,7 +2104,7 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
     if (T > 0 && direct) {
         // direct bins: one wavefront per 64 triangles
         HeavyReg hv;
-        if (L.hmax > 0 && !(dbg & 2048)) {
+        if (L.hmax > 0 && plan->frame_lone && !(dbg & 2048)) {
             hv.ctr = plan->hdr() + 2 + par; hv.flag = plan->hflag(); hv.slots = plan->hslots();
             hv.hmax = (uint32_t)L.hmax;
         }
@@ -2176,13 +2191,13 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     tl.bins = plan->direct();
     tl.capacity = direct ? (uint32_t)L.direct_cap : (uint32_t)L.capacity;
     tl.T = (uint32_t)plan->last_T;
-    const bool split = direct && L.hmax > 0 && !(dbg & 2048);
+    const bool split = direct && L.hmax > 0 && plan->frame_lone && !(dbg & 2048);
     tl.heavy_flag = split ? plan->hflag() : nullptr;
     tl.heavy_slots = split ? plan->hslots() : nullptr;
     tl.heavy_ctr_next = plan->hdr() + 2 + (par ^ 1);
     tl.nhelp = split ? 3 * L.hmax : 0;
     // ordered launches: read the order the previous launch left, leave one for the next
-    const bool ordered = direct && L.ordered && !(dbg & 1024);
+    const bool ordered = direct && L.ordered && plan->frame_lone && !(dbg & 1024);
     const int hp = plan->hint_par;
     tl.order = ordered ? plan->order(hp) : nullptr;
     tl.hint = plan->hint(hp);
@@ -2545,8 +2560,12 @@ int crender_pipeline_frame(crender_pipeline *p, const float *d_tri, const float 
         caller != p->last_caller) {
         // new inputs, or the first frame after a join: whatever produced the inputs, and whatever
         // touched the framebuffers last, was enqueued on the caller's stream
-        CR_HIP(hipEventRecord(p->mark, caller));
-        for (int k = 0; k < p->depth; ++k) CR_HIP(hipStreamWaitEvent(p->s[k], p->mark, 0));
+        // (an event record + cross-stream wait opens a 7-12 us bubble in each queue: skipped when the
+        // caller's stream has nothing pending, e.g. right after the caller synchronised)
+        if (hipStreamQuery(caller) != hipSuccess) {
+            CR_HIP(hipEventRecord(p->mark, caller));
+            for (int k = 0; k < p->depth; ++k) CR_HIP(hipStreamWaitEvent(p->s[k], p->mark, 0));
+        }
         p->last_tri = d_tri; p->last_nrm = d_nrm; p->last_T = T; p->last_caller = caller;
         p->synced = true;
     }

@@ -130,7 +130,8 @@ class _FramePipeline:
                     _capi.check(self.lib.crender_pipeline_bind(
                         self.handle, k, tri.data_ptr(), col.data_ptr(), nrm.data_ptr(), tri.shape[0],
                         filler._P, z.data_ptr(), c.data_ptr(), n.data_ptr(),
-                        None if w is None else w.data_ptr(), _capi.FUSED_CLEAR | filler._extra_flags),
+                        None if w is None else w.data_ptr(),
+                        _capi.FUSED_CLEAR | _capi.OVERLAPPED_FRAMES | filler._extra_flags),
                         "crender_pipeline_bind")
             self._args = (filler._inputs, filler._extra_flags)
         stream = _current_raw_stream(self._index)

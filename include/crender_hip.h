@@ -57,7 +57,17 @@ enum {
      * triangles are binned by appending straight into fixed-capacity per-tile lists (one
      * launch instead of three); a frame that does not fit reports so through
      * crender_plan_last_bin_usage, and the plan then uses the general path by itself. */
-    CRENDER_NO_DIRECT_BINS = 2u
+    CRENDER_NO_DIRECT_BINS = 2u,
+    /* This frame is one of several in flight on the GPU (a swap chain: crender_pipeline_*).  On
+     * frames up to 1024 x 1024 a lone frame is rendered for latency: its raster launch starts the
+     * tiles the previous frame on this plan found covered first, clears the others in groups, and
+     * splits tiles with long lists over several workgroups — all covered tiles then hold a
+     * workgroup slot from the first microsecond to the last, which is the shortest a single frame
+     * gets and leaves no room for a second frame's launch to overlap it.  With this flag the
+     * launch keeps plain raster order and one workgroup per tile (more frames per second, longer
+     * frame).  Pass the same value to crender_prepare and crender_draw.  Results do not depend on
+     * it. */
+    CRENDER_OVERLAPPED_FRAMES = 4u
 };
 
 CRENDER_API int crender_abi_version(void);
