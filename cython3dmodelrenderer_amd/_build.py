@@ -31,6 +31,7 @@ HIPCC_FLAGS = [
     "-fno-gpu-flush-denormals-to-zero",
     "-fno-slp-vectorize",
     "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra",
+    "-Wl,-soname,libcrender_hip.so",
 ]
 
 

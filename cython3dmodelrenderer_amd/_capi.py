@@ -10,11 +10,12 @@ import os
 
 from . import _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, EINVAL, EHIP, ENOMEM = 0, 1, 2, 3
 FUSED_CLEAR = 1
 NO_DIRECT_BINS = 2
 OVERLAPPED_FRAMES = 4
+FUSED_GURO = 8
 
 _vp, _i32, _i64, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint, C.c_size_t
 _f32p = C.POINTER(C.c_float)
@@ -32,6 +33,7 @@ SIGNATURES = {
     "crender_plan_destroy": (None, [_vp]),
     "crender_plan_last_bin_usage": (_i32, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "crender_plan_last_frame_direct": (_i32, [_vp]),
+    "crender_plan_set_light": (_i32, [_vp, _f32p]),
     "crender_plan_timing_begin": (_i32, [_vp, _i32]),
     "crender_plan_timing_end": (_i32, [_vp, _vp, C.POINTER(_i32), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double)]),

@@ -895,7 +895,7 @@ CR_DEV bool fragment16(const Rec16Regs &R, int X, int Y, unsigned long long &key
 // of the projected vertices and its nine edge constants.
 CR_DEV void shade16_store(const Rec16Regs &R, const float *__restrict__ col, const float *__restrict__ nrm,
                           uint32_t tri, int X, int Y, size_t pix,
-                          float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb)
+                          float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb, const Light &Lt)
 {
     float c[9], n[9];
     load9(col + (size_t)tri * 9, c);
@@ -912,14 +912,7 @@ CR_DEV void shade16_store(const Rec16Regs &R, const float *__restrict__ col, con
     float n1, n2, n3, b1, b2, b3;
     numerators(s, X, Y, n1, n2, n3);
     quotients(s, n1, n2, n3, true, b1, b2, b3);
-    zb[pix] = interp(s.z0, s.z1, s.z2, b1, b2, b3);
-    float *cp = cb + pix * 3, *np_ = nb + pix * 3;
-    cp[0] = interp(c[0], c[3], c[6], b1, b2, b3);
-    cp[1] = interp(c[1], c[4], c[7], b1, b2, b3);
-    cp[2] = interp(c[2], c[5], c[8], b1, b2, b3);
-    np_[0] = interp(n[0], n[3], n[6], b1, b2, b3);
-    np_[1] = interp(n[1], n[4], n[7], b1, b2, b3);
-    np_[2] = interp(n[2], n[5], n[8], b1, b2, b3);
+    store_fragment(interp(s.z0, s.z1, s.z2, b1, b2, b3), c, n, b1, b2, b3, Lt, pix, zb, cb, nb);
 }
 
 // The record a 16-lane group is sweeping.  T = TriXYZ (small records: the edge constants are
@@ -1101,6 +1094,7 @@ struct TileLists {
     uint32_t *order_next, *hint_next, *hint_bad_next;
     unsigned char *grouped_next;
     int vec_clear;              // planes 16-byte aligned and W % 4 == 0
+    Light light;                // CRENDER_FUSED_GURO: illumination applied as pixels are stored
 };
 
 // One record of a tile's list: projected vertices, triangle index, pixel box.  false = a stale
@@ -1737,7 +1731,7 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
             id = 0xFFFFu - (low >> 16);
             if (((low >> 8) & 0xFFu) == (((end - beg - 1) / kBatch) & 0xFFu) && !(dbg & 2)) {
                 // the winner's record is still in LDS (it came with the last batch)
-                shade16_store(load_rec16(&recs[low & 0xFFu]), col, nrm, id, x, y, pix, zb, cb, nb);
+                shade16_store(load_rec16(&recs[low & 0xFFu]), col, nrm, id, x, y, pix, zb, cb, nb, L.light);
                 if (win) win[pix] = (int32_t)id;
                 continue;
             }
@@ -1748,7 +1742,7 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
             nb[pix * 3] = 1.0f; nb[pix * 3 + 1] = 1.0f; nb[pix * 3 + 2] = 1.0f;
             continue;
         }
-        shade_and_store(proj, col, nrm, id, x, y, pix, zb, cb, nb);
+        shade_and_store(proj, col, nrm, id, x, y, pix, zb, cb, nb, L.light);
         if (win) win[pix] = (int32_t)id;
     }
     CR_STAMP(3);
@@ -1998,6 +1992,7 @@ struct crender_plan {
     uint32_t *hflag() const { return reinterpret_cast<uint32_t *>(ws + L.off_hflag); }
     uint32_t *hslots() const { return reinterpret_cast<uint32_t *>(ws + L.off_hslots); }
     int hint_par = 0;             // order / hint buffer the next raster launch reads (it writes the other)
+    float light[3] = {0.f, 0.f, 0.f};   // crender_plan_set_light (CRENDER_FUSED_GURO)
     bool frame_lone = true;       // the last bin pass belonged to a frame rendered for latency (no
                                   // CRENDER_OVERLAPPED_FRAMES): ordered dispatch and split heavy tiles
     uint32_t *hint(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_hint) + 4 * k; }
@@ -2209,6 +2204,7 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     if (ordered) plan->hint_par = hp ^ 1;
     const uintptr_t any = (uintptr_t)d_z | (uintptr_t)d_color | (uintptr_t)d_normal | (uintptr_t)d_winner;
     tl.vec_clear = (any & 15u) == 0 && (G.W & 3) == 0;
+    tl.light = Light{plan->light[0], plan->light[1], plan->light[2], (flags & CRENDER_FUSED_GURO) ? 1 : 0};
     const unsigned grid = (unsigned)(G.ntiles + tl.nhelp + (ordered ? 1 : 0));
     if (flags & CRENDER_FUSED_CLEAR)
         hipLaunchKernelGGL((k_raster<TS, true>), dim3(grid), dim3(kThreads), 0, s, proj, d_col, d_nrm, tl,
@@ -2246,6 +2242,10 @@ int raster_pass(crender_plan *plan, const float *proj, const float *d_col, const
 {
     if (!plan) return fail(CRENDER_EINVAL, "null plan");
     if (T != plan->last_T) return fail(CRENDER_EINVAL, "T differs from the prepared frame's");
+    if ((flags & CRENDER_FUSED_GURO) && !(flags & CRENDER_FUSED_CLEAR))
+        return fail(CRENDER_EINVAL, "CRENDER_FUSED_GURO needs CRENDER_FUSED_CLEAR (the reference shades the whole "
+                                    "buffer after every render: only a frame that starts from cleared buffers "
+                                    "can shade its own pixels instead)");
     if (!d_z || !d_color || !d_normal) return fail(CRENDER_EINVAL, "null framebuffer pointer");
     if (T > 0 && (!proj || !d_col || !d_nrm)) return fail(CRENDER_EINVAL, "null triangle array");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2435,6 +2435,13 @@ int crender_plan_last_bin_usage(crender_plan *plan, void *stream, int64_t *neede
     }
     if (needed) *needed = (int64_t)(((unsigned long long)h[4] << 32) | h[0]);
     if (capacity) *capacity = plan->L.capacity;
+    return CRENDER_OK;
+}
+
+int crender_plan_set_light(crender_plan *plan, const float *light3)
+{
+    if (!plan || !light3) return fail(CRENDER_EINVAL, "crender_plan_set_light: bad argument");
+    plan->light[0] = light3[0]; plan->light[1] = light3[1]; plan->light[2] = light3[2];
     return CRENDER_OK;
 }
 

@@ -302,13 +302,52 @@ CR_DEV TriXYZ load_tri(const float *__restrict__ p)
     return TriXYZ{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]};
 }
 
+// f1 fused into the store (CRENDER_FUSED_GURO): guro_illumination.py:20-27 on one pixel, in numpy's
+// float32 operation order — s = (n0*l0 + n1*l1) + n2*l2, m = sqrt((n0*n0 + n1*n1) + n2*n2),
+// f = clip(s / (m + 1e-6), 0, 1) (a NaN stays a NaN), colour *= f.  The normal is stored as it is.
+struct Light {
+    float l0, l1, l2;
+    int on;
+};
+CR_DEV float guro_factor(const Light &L, float n0, float n1, float n2)
+{
+    const float s = (n0 * L.l0 + n1 * L.l1) + n2 * L.l2;
+    const float m = sqrtf((n0 * n0 + n1 * n1) + n2 * n2);
+    float f = s / (m + 1e-6f);
+    f = f < 0.0f ? 0.0f : f;
+    f = f > 1.0f ? 1.0f : f;
+    return f;
+}
+
+// z, colour and normal of a fragment from its barycentrics and the triangle's attributes
+// (.pyx:219, 226-242), with the optional fused illumination.
+CR_DEV void store_fragment(float z, const float c[9], const float n[9], float b1, float b2, float b3,
+                           const Light &L, size_t pix, float *__restrict__ zb, float *__restrict__ cb,
+                           float *__restrict__ nb)
+{
+    zb[pix] = z;
+    float c0 = interp(c[0], c[3], c[6], b1, b2, b3);
+    float c1 = interp(c[1], c[4], c[7], b1, b2, b3);
+    float c2 = interp(c[2], c[5], c[8], b1, b2, b3);
+    const float n0 = interp(n[0], n[3], n[6], b1, b2, b3);
+    const float n1 = interp(n[1], n[4], n[7], b1, b2, b3);
+    const float n2 = interp(n[2], n[5], n[8], b1, b2, b3);
+    if (L.on) {
+        const float f = guro_factor(L, n0, n1, n2);
+        c0 *= f; c1 *= f; c2 *= f;
+    }
+    float *cp = cb + pix * 3, *np_ = nb + pix * 3;
+    cp[0] = c0; cp[1] = c1; cp[2] = c2;
+    np_[0] = n0; np_[1] = n1; np_[2] = n2;
+}
+
 // Recompute the winning fragment of pixel (X, Y) and store z, colour, normal
 // (.pyx:219, 226-242).  Same device functions as the coverage pass, so z is the very
 // value the key was built from.
 CR_DEV void shade_and_store(const float *__restrict__ proj, const float *__restrict__ col,
                             const float *__restrict__ nrm, uint32_t tri, int X, int Y,
                             size_t pix, float *__restrict__ zb, float *__restrict__ cb,
-                            float *__restrict__ nb)
+                            float *__restrict__ nb, const Light &L = Light{0.f, 0.f, 0.f, 0})
 {
     const TriXYZ t = load_tri(proj + (size_t)tri * 9);
     float c[9], n[9];
@@ -316,14 +355,7 @@ CR_DEV void shade_and_store(const float *__restrict__ proj, const float *__restr
     load9(nrm + (size_t)tri * 9, n);
     float b1, b2, b3;
     barycentric(t, X, Y, b1, b2, b3);
-    zb[pix] = interp(t.z0, t.z1, t.z2, b1, b2, b3);
-    float *cp = cb + pix * 3, *np_ = nb + pix * 3;
-    cp[0] = interp(c[0], c[3], c[6], b1, b2, b3);
-    cp[1] = interp(c[1], c[4], c[7], b1, b2, b3);
-    cp[2] = interp(c[2], c[5], c[8], b1, b2, b3);
-    np_[0] = interp(n[0], n[3], n[6], b1, b2, b3);
-    np_[1] = interp(n[1], n[4], n[7], b1, b2, b3);
-    np_[2] = interp(n[2], n[5], n[8], b1, b2, b3);
+    store_fragment(interp(t.z0, t.z1, t.z2, b1, b2, b3), c, n, b1, b2, b3, L, pix, zb, cb, nb);
 }
 
 }  // namespace crender

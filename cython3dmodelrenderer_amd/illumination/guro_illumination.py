@@ -5,7 +5,9 @@
 
 ``draw_illumination`` is the numpy form on host arrays (same call sequence as the
 reference, so the same bits); ``draw_illumination_device`` runs the HIP kernel
-``crender_guro_illumination`` on the filler's device buffers.
+``crender_guro_illumination`` on the filler's device buffers; ``fuse_into`` hands the light
+to the filler, whose cleared frames then shade each pixel as the raster kernel stores it
+(CRENDER_FUSED_GURO: no second pass over the colour and normal planes).
 """
 import ctypes as C
 
@@ -35,4 +37,8 @@ class GuroIllumination(IlluminationDrawer):
             filler.color_buffer.data_ptr(), filler.normals_buffer.data_ptr(), light,
             filler.h, filler.w, filler.y0, filler.y1, filler._stream()), "crender_guro_illumination")
         filler._host_fresh = False
+        return True
+
+    def fuse_into(self, filler):
+        filler.set_fused_illumination(self.light_direction)
         return True

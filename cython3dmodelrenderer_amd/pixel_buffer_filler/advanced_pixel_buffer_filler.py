@@ -8,9 +8,12 @@ crender/cy/pixel_buffer_filler/advanced_pixel_buffer_filler.pyx:20-253 of the re
     .get_normals_buffer()  .get_color_buffer()  .get_z_buffer()
 
 The framebuffers and the model arrays live in HBM as torch-ROCm tensors; every call
-goes through the C ABI of libcrender_hip.so (include/crender_hip.h).  torch supplies
-device memory and the HIP stream only.  There is no CPU path: without the HIP library
-or a GPU the constructor raises.
+goes through the C ABI of libcrender_hip.so (include/crender_hip.h) — the per-frame calls
+(render_model, the swap chain's submit) through the torch C++ extension ``crender_torch``
+(csrc/crender_torch.cpp), which unwraps the tensors and torch's current stream and calls the
+same C entry points; plan management and the rarely used calls through ctypes.  torch supplies
+device memory and the HIP stream only.  There is no CPU path: without the HIP library, the
+extension or a GPU the constructor raises.
 
 Behaviour kept from the reference
   * buffers persist across ``render_model`` calls and are never cleared, so successive
@@ -37,7 +40,7 @@ import os
 import numpy as np
 import torch
 
-from .. import _capi
+from .. import _capi, _torch_ext
 
 
 def _as_device_f32(a, name, device):
@@ -108,7 +111,8 @@ class _FramePipeline:
         self.n = 0
         self.pending = False
         self._args = None          # (inputs, flags) the slots are bound to
-        self._submit = self.lib.crender_pipeline_submit
+        self._submit = filler._ext.pipeline_submit       # (handle, device index): torch's current stream
+        self._handle_int = self.handle.value
         self._index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
     def close(self):
@@ -120,28 +124,27 @@ class _FramePipeline:
         self.plans = []
 
     def frame(self, filler):
-        if self._args is None or self._args[0] is not filler._inputs or self._args[1] != filler._extra_flags:
+        want = (filler._inputs, filler._extra_flags, filler._fused_light)
+        if self._args is None or self._args[0] is not want[0] or self._args[1:] != want[1:]:
             # everything but the stream is fixed while the resident model is: bind the arguments
             # of every slot once, the per-frame call then passes two (ctypes spends ~0.3 us per
             # argument; twelve per frame were a third of the host's time per frame)
             tri, col, nrm = filler._inputs
-            with torch.cuda.device(self.device):
-                for k, (z, c, n, w) in enumerate(self.sets):
-                    _capi.check(self.lib.crender_pipeline_bind(
-                        self.handle, k, tri.data_ptr(), col.data_ptr(), nrm.data_ptr(), tri.shape[0],
-                        filler._P, z.data_ptr(), c.data_ptr(), n.data_ptr(),
-                        None if w is None else w.data_ptr(),
-                        _capi.FUSED_CLEAR | _capi.OVERLAPPED_FRAMES | filler._extra_flags),
-                        "crender_pipeline_bind")
-            self._args = (filler._inputs, filler._extra_flags)
-        stream = _current_raw_stream(self._index)
+            guro = 0
+            if filler._fused_light is not None:
+                guro = _capi.FUSED_GURO
+                for plan in self.plans:
+                    _capi.check(self.lib.crender_plan_set_light(plan, (C.c_float * 3)(*filler._fused_light)),
+                                "crender_plan_set_light")
+            for k, (z, c, n, w) in enumerate(self.sets):
+                filler._ext.pipeline_bind(self.handle.value, k, tri, col, nrm, filler._P_t, z, c, n, w,
+                                          _capi.FUSED_CLEAR | _capi.OVERLAPPED_FRAMES | guro | filler._extra_flags)
+            self._args = want
         if _current_device() == self._index:
-            rc = self._submit(self.handle, stream)
+            self._submit(self._handle_int, self._index)
         else:                              # the library launches on the calling thread's device
             with torch.cuda.device(self.device):
-                rc = self._submit(self.handle, stream)
-        if rc:
-            _capi.check(rc, "crender_pipeline_submit")
+                self._submit(self._handle_int, self._index)
         # the filler's buffers are now this frame's
         filler.z_buffer, filler.color_buffer, filler.normals_buffer, filler.winner_buffer = self.sets[self.k]
         self.k = (self.k + 1) % self.depth
@@ -175,6 +178,7 @@ class AdvancedPixelBufferFiller:
                  device=None, tile=0, row_strip=None, track_winner=False, cache_inputs=False,
                  bin_capacity=0, direct_bins=True, pipeline=False, pipeline_depth=None):
         self._lib = _capi.load()                      # raises if the HIP library is missing
+        self._ext = _torch_ext.load()                 # raises if the torch extension is not built
         if not torch.cuda.is_available():
             raise _capi.CrenderError("AdvancedPixelBufferFiller needs a ROCm GPU (no CPU fallback)")
         self.h, self.w = int(h), int(w)
@@ -192,6 +196,7 @@ class AdvancedPixelBufferFiller:
                                                         self.h, self.w, P), "crender_projection_matrix")
         self._P = P
         self.proj_mat = np.array(P[:], dtype=np.float32).reshape(4, 4)
+        self._P_t = torch.from_numpy(self.proj_mat.reshape(16).copy())      # host tensor for the extension
 
         with torch.cuda.device(self.device):
             # same initial state as __cinit__ (.pyx:65-67)
@@ -212,6 +217,8 @@ class AdvancedPixelBufferFiller:
         self._host_fresh = False       # mirrors equal the device buffers
         self._host_exposed = False     # a mirror was handed out and may have been edited
         self._unverified = False       # a frame was launched whose bin lists have not been checked
+        self._fused_light = None       # (l0, l1, l2): illumination fused into cleared frames
+        self._plan_light = None        # what the single-stream plan currently holds
         self._pipeline = bool(pipeline)  # render_frame(): overlap consecutive frames (see _FramePipeline)
         if not pipeline_depth:
             # measured on MI355X (scripts/ab_depth.sh): three frames in flight, or four for small
@@ -305,11 +312,16 @@ class AdvancedPixelBufferFiller:
         tri, col, nrm = self._inputs
         T = tri.shape[0]
         self._ensure_plan(T)
-        with torch.cuda.device(self.device):
-            _capi.check(self._lib.crender_render_model(
-                self._plan, tri.data_ptr(), col.data_ptr(), nrm.data_ptr(), T, self._P,
-                self.z_buffer.data_ptr(), self.color_buffer.data_ptr(), self.normals_buffer.data_ptr(),
-                self._win_ptr(), flags | self._extra_flags, self._stream()), "crender_render_model")
+        if (flags & _capi.FUSED_CLEAR) and self._fused_light is not None:
+            if self._plan_light != (self._plan.value, self._fused_light):
+                _capi.check(self._lib.crender_plan_set_light(self._plan, (C.c_float * 3)(*self._fused_light)),
+                            "crender_plan_set_light")
+                self._plan_light = (self._plan.value, self._fused_light)
+            flags |= _capi.FUSED_GURO
+        # (the extension unwraps the tensors, takes torch's current stream of their device and
+        # calls crender_render_model)
+        self._ext.render_model(self._plan.value, tri, col, nrm, self._P_t, self.z_buffer, self.color_buffer,
+                               self.normals_buffer, self.winner_buffer, flags | self._extra_flags)
         self._last_flags = flags
         self._host_fresh = False
         self._unverified = True
@@ -363,8 +375,9 @@ class AdvancedPixelBufferFiller:
     def get_size(self):
         return self.h, self.w
 
-    def render_model(self, model, refresh=False):
-        """Project and rasterize ``model`` on top of the current buffers (.pyx:92-104)."""
+    def render_model(self, model, refresh=False, clear=False):
+        """Project and rasterize ``model`` on top of the current buffers (.pyx:92-104);
+        ``clear=True`` (extension) renders into freshly initialised buffers in the same pass."""
         src = (model._vertices_by_triangles, model._colors_by_triangles, model._normals_by_triangles)
         key = tuple((id(a), getattr(a, "shape", None)) for a in src)
         if refresh or not self.cache_inputs or key != self._input_key:
@@ -377,8 +390,11 @@ class AdvancedPixelBufferFiller:
             self._input_refs = src         # keep ids alive while the key is cached
         else:
             inputs = None
-        self._push_host_edits()
-        self._launch(0, inputs)            # (a pending overflow check needs the OLD inputs first)
+        if clear:
+            self._host_exposed = False
+        else:
+            self._push_host_edits()
+        self._launch(_capi.FUSED_CLEAR if clear else 0, inputs)   # (a pending overflow check needs the OLD inputs first)
         if self._host:
             # arrays handed out earlier are views of the reference's own buffers there: they show
             # this render too
@@ -408,6 +424,17 @@ class AdvancedPixelBufferFiller:
         else:
             self._push_host_edits()
         self._launch(_capi.FUSED_CLEAR if clear else 0, inputs)
+
+    def set_fused_illumination(self, light_direction=None):
+        """Fuse ``GuroIllumination(light_direction).draw_illumination`` into every frame that starts
+        from cleared buffers (``render_arrays(..., clear=True)``, ``render_model(..., clear=True)``,
+        ``render_frame``): colour is shaded as it is stored, instead of in a second pass over the
+        colour and normal planes.  ``light_direction`` is the illumination object's own
+        (flipped, normalised) vector; ``None`` switches the fusion off.  Frames that composite on
+        older content are never fused (the reference shades the whole buffer again after every
+        render)."""
+        self._join_pipe()
+        self._fused_light = None if light_direction is None else tuple(float(v) for v in light_direction)
 
     def render_frame(self, pipelined=None):
         """One benchmark frame: clear + project + rasterize the resident model

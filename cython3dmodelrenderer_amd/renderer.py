@@ -15,6 +15,8 @@ class Renderer:
         self.use_tqdm = use_tqdm
         # on_device=True keeps shading on the GPU and returns the colour TENSOR; the default
         # reproduces the reference's data flow through writable numpy buffers.
+        # on_device="fused": one model per frame — the frame starts from cleared buffers and the
+        # raster kernel shades each pixel as it stores it (no illumination pass at all).
         self.on_device = on_device
 
     def render(self, model, normalize_model=False, random_colors=True):
@@ -25,6 +27,10 @@ class Renderer:
             model.scale(span / model.get_max_span())
             model.shift(-model.get_mean_vertex() + [centre[0], centre[1], -span])
         filler = self.pixel_buffer_filler
+        if self.on_device == "fused" and getattr(self.illumination, "fuse_into", None):
+            self.illumination.fuse_into(filler)
+            filler.render_model(model, clear=True)
+            return filler.get_color_tensor()
         filler.render_model(model)
         if self.on_device and self.illumination.draw_illumination_device(filler):
             return filler.get_color_tensor()

@@ -3,7 +3,8 @@
 
     python examples/run.py /path/to/objects/T-Rex.obj output.png [size]
 
-Model -> AdvancedPixelBufferFiller (HIP) -> GuroIllumination (HIP) -> flip + uint8 (HIP) -> PNG.
+Model -> AdvancedPixelBufferFiller (HIP, GuroIllumination fused into the raster kernel's stores)
+-> flip + uint8 (HIP) -> PNG.
 The .obj / .mtl / texture assets are the reference's; they are not part of this repository.
 """
 import os
@@ -33,7 +34,7 @@ def main():
     fit_model(model)
     t1 = time.perf_counter()
     filler = AdvancedPixelBufferFiller(size, size, fov=45, n_threads=8)
-    renderer = Renderer(filler, GuroIllumination([0, 0, 1]), None, *filler.get_size(), on_device=True)
+    renderer = Renderer(filler, GuroIllumination([0, 0, 1]), None, *filler.get_size(), on_device="fused")
     renderer.render(model)
     image_bgr = filler.present_u8().cpu().numpy()          # == image[::-1].astype('uint8')
     t2 = time.perf_counter()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CRENDER_ABI_VERSION 1
+#define CRENDER_ABI_VERSION 2
 #define CRENDER_API __attribute__((visibility("default")))
 
 enum {
@@ -67,7 +67,15 @@ enum {
      * launch keeps plain raster order and one workgroup per tile (more frames per second, longer
      * frame).  Pass the same value to crender_prepare and crender_draw.  Results do not depend on
      * it. */
-    CRENDER_OVERLAPPED_FRAMES = 4u
+    CRENDER_OVERLAPPED_FRAMES = 4u,
+    /* next row f1 fused: apply GuroIllumination.draw_illumination
+     * (guro_illumination.py:20-27) to every pixel as it is stored — colour *= clip(n.l / (|n| +
+     * 1e-6), 0, 1) with the light vector of crender_plan_set_light, in numpy's float32 operation
+     * order — instead of in a second pass over the colour and normal planes (36 B/pixel).  Only
+     * with CRENDER_FUSED_CLEAR: the reference shades the WHOLE buffer after every render, which a
+     * frame can only reproduce pixel by pixel when it starts from cleared buffers (background
+     * colour 0 stays 0).  Same result as the render followed by crender_guro_illumination. */
+    CRENDER_FUSED_GURO = 8u
 };
 
 CRENDER_API int crender_abi_version(void);
@@ -116,6 +124,10 @@ CRENDER_API int crender_plan_last_bin_usage(crender_plan *plan, void *stream,
                                 int64_t *needed, int64_t *capacity);
 
 CRENDER_API int crender_plan_last_frame_direct(crender_plan *plan);
+
+/* Light direction (host pointer to 3 floats, copied) for frames rendered with CRENDER_FUSED_GURO:
+ * GuroIllumination.__init__'s light_direction (guro_illumination.py:6-18). */
+CRENDER_API int crender_plan_set_light(crender_plan *plan, const float *light3);
 
 /* Measurement aid (no reference counterpart): record HIP events on the frame's own
  * stream around the binning passes and around the raster kernel of each of the next

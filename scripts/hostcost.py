@@ -25,4 +25,7 @@ pipe = f._pipe
 timed("pipe.frame(filler)", lambda: pipe.frame(f))
 lib = pipe.lib
 stream = torch.cuda.current_stream().cuda_stream
-timed("lib.crender_pipeline_submit(handle, stream)", lambda: lib.crender_pipeline_submit(pipe.handle, stream))
+timed("ctypes crender_pipeline_submit(handle, stream)", lambda: lib.crender_pipeline_submit(pipe.handle, stream))
+ext = f._ext
+h, idx = pipe.handle.value, pipe._index
+timed("crender_torch.pipeline_submit(handle, device)", lambda: ext.pipeline_submit(h, idx))

@@ -36,6 +36,26 @@ def test_library_exports_every_declared_symbol(capi):
     assert L.crender_abi_version() == capi.ABI_VERSION
 
 
+def test_torch_extension_is_built_and_bound():
+    """The torch C++ extension over the C ABI (csrc/crender_torch.cpp): builds in-tree without a
+    GPU, loads, links the same libcrender_hip.so, and exposes the per-frame entry points."""
+    from cython3dmodelrenderer_amd import _capi, _torch_ext
+    if _torch_ext.needs_build():
+        _torch_ext.build()
+    m = _torch_ext.load()
+    assert m.abi_version() == _capi.ABI_VERSION
+    for name in ("render_model", "pipeline_bind", "pipeline_submit", "pipeline_join"):
+        assert callable(getattr(m, name))
+    with open("/proc/self/maps") as fh:
+        maps = fh.read()
+    assert "crender_torch" in maps and "libcrender_hip.so" in maps
+    # argument checks run before anything touches a device
+    import torch
+    z = torch.zeros(4)
+    with pytest.raises(RuntimeError):
+        m.render_model(0, z, z, z, torch.zeros(16), z, z, z, None, 0)
+
+
 def test_library_contains_gfx950_code_object(capi):
     data = open(capi.lib_path(), "rb").read()
     assert b"gfx950" in data
