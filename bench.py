@@ -9,12 +9,14 @@ Default workload: T-Rex.obj at 1024x1024, fov 45 (configs[1], the README benchma
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
 N > 1 (launched by torch.distributed.run, one rank per GPU), two modes:
-  --mode frames (default)  every rank renders its own full frames, no collective in the data
-                           path: "weak" scaling, value = frames of all ranks per second;
-  --mode strips            north_star's layout: ONE frame per step, sharded into row strips, the
-                           strips all-gathered with RCCL: "strong" scaling.  The all-gather moves
-                           28 B/pixel to every rank, which costs more than rendering the frame on
-                           one GPU, hence not the default.
+  --mode strips (default)  north_star's layout: ONE frame per step, sharded into row strips, the
+                           finished strips exchanged with RCCL: "strong" scaling.  Default workload
+                           for N > 1 is T-Rex 8192x8192 (configs[3]).  --exchange picks what is
+                           gathered (planes 28 B/pixel, color 12, present 3), --chunks N gathers
+                           sub-strips on a second stream while the next one is rasterized.  The same
+                           JSON line carries the step time without the exchange;
+  --mode frames            every rank renders its own full frames, no collective in the data
+                           path: "weak" scaling, value = frames of all ranks per second.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the raster kernel against HBM bandwidth
 with the algorithmic bytes of SURVEY.md section 8d (108 B per triangle read once + 28 B per
@@ -103,8 +105,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="trex1024",
-                    choices=["cube256", "trex1024", "bunny4096", "trex8192", "synth10m"])
+    ap.add_argument("--workload", default=None,
+                    choices=["cube256", "trex1024", "bunny4096", "trex8192", "synth10m"],
+                    help="default: trex1024 on one GPU (BASELINE.json's metric config), trex8192 "
+                         "(configs[3], the sharded frame) on several")
     ap.add_argument("--synth-triangles", type=int, default=10_000_000)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--max-triangles", type=int, default=-1,
@@ -120,11 +124,17 @@ def main():
                          "launch contract on a box with fewer GPUs than ranks: ranks share devices "
                          "(LOCAL_RANK modulo the device count) and host-side collectives carry the "
                          "timings; --mode strips then needs --no-gather")
-    ap.add_argument("--mode", default="frames", choices=["frames", "strips"],
-                    help="N>1: 'frames' (default) = every rank renders its own full frame per step, no "
-                         "collective in the data path (weak scaling); 'strips' = ONE frame per step, "
-                         "row strips + RCCL all-gather of the planes (north_star's layout; strong "
-                         "scaling).  See DESIGN.md section 5 for why frames is the default.")
+    ap.add_argument("--mode", default="strips", choices=["frames", "strips"],
+                    help="N>1: 'strips' (default) = ONE frame per step, row strips + RCCL exchange of "
+                         "the finished strips (north_star's layout; strong scaling); 'frames' = every "
+                         "rank renders its own full frame per step, no collective in the data path "
+                         "(weak scaling)")
+    ap.add_argument("--exchange", default="planes", choices=["planes", "color", "present"],
+                    help="strips: what every rank receives — the three planes (28 B/pixel), the colour "
+                         "plane (12) or the presented uint8 image (3)")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="strips: sub-strips per rank, each exchanged on a second stream while the "
+                         "next one is rasterized")
     args = ap.parse_args()
 
     # more hardware queues than the runtime's default of 4, so that four streams of the swap
@@ -144,6 +154,8 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N "
                              "--master-addr 127.0.0.1 bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.workload is None:
+        args.workload = "trex1024" if world == 1 else "trex8192"
     if args.backend == "gloo":
         local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
@@ -153,9 +165,7 @@ def main():
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
-            if args.mode == "strips" and not args.no_gather:
-                raise SystemExit("--backend gloo cannot all-gather device planes: add --no-gather")
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo")      # (strips are then staged through the host)
 
     tri, col, nrm, (H, W), fov = scenes.scene(args.workload, synth_T=args.synth_triangles)
     if args.max_triangles >= 0:
@@ -163,25 +173,33 @@ def main():
     T = int(tri.shape[0])
     strips = world > 1 and args.mode == "strips"
     y0, y1 = D.strip_rows(H, world, rank) if strips else (0, H)
-    filler = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile,
-                                       row_strip=(y0, y1) if strips else None,
-                                       pipeline=not args.no_pipeline,
-                                       pipeline_depth=args.pipeline_depth)
+    if strips:
+        sr = D.StripRenderer(H, W, rank, world, fov=fov, device=device, tile=args.tile,
+                             exchange=args.exchange, chunks=args.chunks,
+                             pipeline=not args.no_pipeline)
+        filler = sr.filler
+    else:
+        sr = None
+        filler = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile,
+                                           pipeline=not args.no_pipeline,
+                                           pipeline_depth=args.pipeline_depth)
 
-    def step(pipelined=True):
-        filler.render_frame(pipelined=pipelined)
-        if strips and not args.no_gather:
-            filler.join()            # the collective runs on this stream, the frame on the pipeline's
-            D.all_gather_strips([filler.z_buffer, filler.color_buffer, filler.normals_buffer],
-                                H, rank, world)
+    def step(pipelined=True, gather=True):
+        if sr is not None:
+            sr.render_frame(gather=gather and not args.no_gather)
+        else:
+            filler.render_frame(pipelined=pipelined)
 
     # set-up, untimed and not a step: upload the model, size the bin lists, and create the swap
     # chain's plans / streams / framebuffer sets (allocation must not land in the timed region
     # when the driver asks for --warmup 0)
-    filler.render_arrays(tri, col, nrm, clear=True)
-    filler.synchronize()
-    if not args.no_pipeline:
-        filler.render_frame()
+    if sr is not None:
+        sr.set_model_arrays(tri, col, nrm)
+    else:
+        filler.render_arrays(tri, col, nrm, clear=True)
+        filler.synchronize()
+    if not args.no_pipeline and not (sr is not None and sr.empty):
+        step()
         filler.synchronize()
     for _ in range(args.warmup):
         step()
@@ -201,24 +219,37 @@ def main():
     elapsed = time.perf_counter() - t0
     assert not (filler._pipe is not None and filler._pipe.overflowed(filler)), \
         "bin lists overflowed inside the timed region"
+    if filler._pipe is not None:
+        filler._pipe.n = 0
 
     # ---- per-kernel durations: the same K steps again with HIP events on the frame's stream
     # around the binning passes and around the raster kernel (single stream, not pipelined, so
     # each kernel's duration is its own).  Kept out of the timed region
     # above because the three event records cost ~11 us per frame on a ~35 us frame (measured:
     # scripts/hostoverhead.py vs this loop); the events loop's own frame time is reported too.
-    step(pipelined=False)            # also makes sure the single-stream plan exists
+    elapsed_render_only = None
+    if strips:
+        # the same K steps without the exchange: what the rasterization of the sharded frame costs
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            step(gather=False)
+        barrier()
+        elapsed_render_only = time.perf_counter() - t3
+    if sr is not None and sr.empty:
+        raise SystemExit("more ranks than rows")
+    step(pipelined=False, gather=False)            # also makes sure the single-stream plan exists
     barrier()
     t2 = time.perf_counter()         # the same K frames one at a time on one stream: frame latency
     for _ in range(args.steps):
-        step(pipelined=False)
+        filler.render_frame(pipelined=False)
     barrier()
     elapsed_single = time.perf_counter() - t2
     filler.timing_begin(args.steps)
     barrier()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        step(pipelined=False)
+        filler.render_frame(pipelined=False)
     barrier()
     elapsed_events = time.perf_counter() - t1
     n_timed, bin_ms, raster_ms = filler.timing_end()
@@ -226,10 +257,12 @@ def main():
     assert need <= cap, "bin lists overflowed inside the timing pass"
 
     if world > 1:
-        t = torch.tensor([elapsed, raster_ms, bin_ms], dtype=torch.float64,
+        t = torch.tensor([elapsed, raster_ms, bin_ms, elapsed_render_only or 0.0], dtype=torch.float64,
                          device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, raster_ms, bin_ms = (float(v) for v in t.cpu())
+        elapsed, raster_ms, bin_ms, ero = (float(v) for v in t.cpu())
+        if elapsed_render_only is not None:
+            elapsed_render_only = ero
 
     if rank == 0:
         frames_per_step = 1 if (world == 1 or strips) else world
@@ -252,9 +285,11 @@ def main():
             "metric": "frames/sec", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_without_exchange": (elapsed_render_only / args.steps * 1e3
+                                             if elapsed_render_only is not None else None),
             "higher_is_better": True,
             # strips: the job is ONE frame however many GPUs share its rows; frames: one per rank
-            "scaling": "strong" if args.mode == "strips" else "weak",
+            "scaling": "strong" if strips else "weak",
             "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if args.workload == "synth10m" else
             "T-Rex/bunny/cube input arrays committed under tests/golden (made from the reference's "
@@ -262,8 +297,9 @@ def main():
             "config": {"workload": args.workload, "triangles": T, "height": H, "width": W,
                        "fov": fov, "row_strips": world if strips else 1,
                        "multi_gpu": ("single GPU" if world == 1 else
-                                     "row strips + RCCL all-gather of the three planes" if strips else
-                                     "independent full frames per rank, no collective"),
+                                     f"row strips + {'gloo (host-staged)' if args.backend == 'gloo' else 'RCCL'} "
+                                     f"all-gather, exchange = {args.exchange}, {args.chunks} sub-strip(s) per rank"
+                                     if strips else "independent full frames per rank, no collective"),
                        "tile": filler.tile or "auto",
                        "frame": "clear + project + rasterize, model resident in HBM",
                        "pipelined": (False if args.no_pipeline else
