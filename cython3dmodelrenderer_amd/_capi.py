@@ -53,6 +53,10 @@ SIGNATURES = {
     "crender_selfcheck_division": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "crender_present_u8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "crender_guro_illumination": (_i32, [_vp, _vp, _f32p, _i32, _i32, _i32, _i32, _vp]),
+    "crender_model_shift": (_i32, [_vp, _i64, C.POINTER(C.c_double), _i32, _vp]),
+    "crender_model_scale": (_i32, [_vp, _i64, _vp, C.c_float, _i32, _vp]),
+    "crender_model_stats": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "crender_model_gather": (_i32, [_vp, _vp, _vp, _i64, _vp]),
 }
 
 _lib = None

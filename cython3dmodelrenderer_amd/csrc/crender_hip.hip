@@ -1884,6 +1884,87 @@ __global__ __launch_bounds__(kThreads) void k_present_u8(const float *__restrict
     }
 }
 
+// ---- f2: model transforms on resident vertex buffers (reference: cy/data_structures/model.py:153-236)
+// shift / scale / mean vertex / max span / the *_by_triangles gathers, each in numpy's own float32
+// (or, where numpy promotes, float64) operation order, so that a device-resident model hands the
+// filler the very arrays the reference's Model would (tests: bit for bit against the host Model).
+// rotate and the vertex-normal computation stay on the host (they go through BLAS
+// kernels whose summation order is not a property of the reference).
+__global__ __launch_bounds__(kThreads) void k_model_shift(float *__restrict__ v, size_t n, double s0, double s1,
+                                                          double s2, int in_double)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const int c = (int)(i % 3);
+        const double s = c == 0 ? s0 : c == 1 ? s1 : s2;
+        // vertices + shift: float32 + float32 array stays float32; a Python list or a float64
+        // array promotes the sum to float64, rounded once when the Model stores float32
+        v[i] = in_double ? (float)((double)v[i] + s) : v[i] + (float)s;
+    }
+}
+
+// vtx -= mean; vtx *= coef; vtx += mean, three float32 passes in place (model.py:222-228)
+__global__ __launch_bounds__(kThreads) void k_model_scale(float *__restrict__ v, size_t n,
+                                                          const float *__restrict__ mean3, float coef, int keep)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        float x = v[i];
+        if (keep) {
+            const float m = mean3[i % 3];
+            x = x - m;
+            x = x * coef;
+            x = x + m;
+        } else {
+            x = x * coef;
+        }
+        v[i] = x;
+    }
+}
+
+// vertices.mean(axis=0): numpy adds the rows one after another into a float32 accumulator per
+// component (no pairwise summation along a strided axis) and divides by the intp count in
+// float64, stored as float32.  One lane per component, sequential.
+__global__ void k_model_mean(const float *__restrict__ v, int64_t V, float *__restrict__ mean3)
+{
+    const int c = threadIdx.x;
+    if (c >= 3) return;
+    float acc = 0.0f;
+    for (int64_t i = 0; i < V; ++i) acc = acc + v[i * 3 + c];
+    mean3[c] = (float)((double)acc / (double)V);
+}
+
+// max over vertices of ||v - mean|| with numpy's float32 norm: sqrt((dx*dx + dy*dy) + dz*dz).
+// Non-negative floats order like their bit patterns: an unsigned atomic max is exact.
+__global__ __launch_bounds__(kThreads) void k_model_max_span(const float *__restrict__ v, int64_t V,
+                                                             const float *__restrict__ mean3,
+                                                             uint32_t *__restrict__ out_bits)
+{
+    const float m0 = mean3[0], m1 = mean3[1], m2 = mean3[2];
+    float best = 0.0f;
+    bool nan = false;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < V; i += stride) {
+        const float dx = v[i * 3] - m0, dy = v[i * 3 + 1] - m1, dz = v[i * 3 + 2] - m2;
+        const float r = sqrtf((dx * dx + dy * dy) + dz * dz);
+        if (r != r) nan = true;          // np.max propagates a NaN
+        else if (r > best) best = r;
+    }
+    atomicMax(out_bits, nan ? 0x7FC00000u : __float_as_uint(best));
+}
+
+// out[t][k][:] = attr[index[t][k]][:]  (vertices[faces], normals[faces_n], colours[faces_t])
+__global__ __launch_bounds__(kThreads) void k_model_gather(const float *__restrict__ attr,
+                                                           const int32_t *__restrict__ index,
+                                                           float *__restrict__ out, int64_t n_corners)
+{
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_corners; i += stride) {
+        const int64_t j = index[i];
+        out[i * 3] = attr[j * 3]; out[i * 3 + 1] = attr[j * 3 + 1]; out[i * 3 + 2] = attr[j * 3 + 2];
+    }
+}
+
 // ---- host side --------------------------------------------------------------------
 constexpr size_t kAlign = 256;
 size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
@@ -2676,6 +2757,55 @@ int crender_guro_illumination(float *d_color, const float *d_normal, const float
                        static_cast<hipStream_t>(stream), d_color, d_normal, light3[0], light3[1],
                        light3[2], first, npix);
     CR_LAUNCH_CHECK("k_guro");
+    return CRENDER_OK;
+}
+
+// ---- f2: model transforms (cy/data_structures/model.py:153-236) -----------------------------------
+int crender_model_shift(float *d_vertices, int64_t V, const double *shift3, int shift_is_float32, void *stream)
+{
+    if (V < 0 || !shift3 || (V > 0 && !d_vertices)) return fail(CRENDER_EINVAL, "crender_model_shift: bad argument");
+    if (V == 0) return CRENDER_OK;
+    hipLaunchKernelGGL(k_model_shift, dim3(grid_for((size_t)V * 3, 4096)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), d_vertices, (size_t)V * 3, shift3[0], shift3[1],
+                       shift3[2], shift_is_float32 ? 0 : 1);
+    CR_LAUNCH_CHECK("k_model_shift");
+    return CRENDER_OK;
+}
+
+int crender_model_scale(float *d_vertices, int64_t V, const float *d_mean3, float coef, int keep_position,
+                        void *stream)
+{
+    if (V < 0 || (V > 0 && !d_vertices) || (keep_position && !d_mean3))
+        return fail(CRENDER_EINVAL, "crender_model_scale: bad argument");
+    if (V == 0) return CRENDER_OK;
+    hipLaunchKernelGGL(k_model_scale, dim3(grid_for((size_t)V * 3, 4096)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), d_vertices, (size_t)V * 3, d_mean3, coef, keep_position);
+    CR_LAUNCH_CHECK("k_model_scale");
+    return CRENDER_OK;
+}
+
+int crender_model_stats(const float *d_vertices, int64_t V, float *d_mean3, float *d_max_span, void *stream)
+{
+    if (V <= 0 || !d_vertices || !d_mean3 || !d_max_span)
+        return fail(CRENDER_EINVAL, "crender_model_stats: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_model_mean, dim3(1), dim3(64), 0, s, d_vertices, V, d_mean3);
+    CR_LAUNCH_CHECK("k_model_mean");
+    CR_HIP(hipMemsetAsync(d_max_span, 0, sizeof(float), s));
+    hipLaunchKernelGGL(k_model_max_span, dim3(grid_for((size_t)V, 1024)), dim3(kThreads), 0, s, d_vertices, V,
+                       d_mean3, reinterpret_cast<uint32_t *>(d_max_span));
+    CR_LAUNCH_CHECK("k_model_max_span");
+    return CRENDER_OK;
+}
+
+int crender_model_gather(const float *d_attr, const int32_t *d_index, float *d_out, int64_t T, void *stream)
+{
+    if (T < 0 || (T > 0 && (!d_attr || !d_index || !d_out)))
+        return fail(CRENDER_EINVAL, "crender_model_gather: bad argument");
+    if (T == 0) return CRENDER_OK;
+    hipLaunchKernelGGL(k_model_gather, dim3(grid_for((size_t)T * 3, 4096)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), d_attr, d_index, d_out, T * 3);
+    CR_LAUNCH_CHECK("k_model_gather");
     return CRENDER_OK;
 }
 

@@ -6,4 +6,12 @@ from . import model as _model
 
 Model = _model.Model
 
-__all__ = ["Model"]
+
+def __getattr__(name):            # DeviceModel pulls in torch: imported on first use
+    if name == "DeviceModel":
+        from .device_model import DeviceModel
+        return DeviceModel
+    raise AttributeError(name)
+
+
+__all__ = ["Model", "DeviceModel"]

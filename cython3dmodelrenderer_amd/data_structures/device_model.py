@@ -1,0 +1,123 @@
+"""Device-resident ``Model``: the reference's mesh container
+(crender/cy/data_structures/model.py:118-256) with its vertex, index and normal arrays kept in HBM
+and the transforms that are exactly reproducible there running as HIP kernels:
+
+    shift, scale, the mean vertex, the max span, and the three ``*_by_triangles`` gathers
+
+each in numpy's own operation order (float32 elementwise; float64 where numpy promotes; the mean
+as numpy's row-after-row float32 sum), so the arrays handed to the filler are, bit for bit, what
+the host ``Model`` produces.  ``rotate`` — and with it the vertex-normal computation it triggers —
+runs on the host ``Model`` and re-uploads (its float32 x float64 ``matmul`` and the ``np.dot``
+threshold of the normal de-duplication go through BLAS kernels whose summation order is not a
+property of the reference).
+
+The filler takes torch tensors as they are: ``render_model(device_model)`` uploads nothing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _capi
+from .model import Model
+
+
+class DeviceModel:
+    def __init__(self, model: Model, device="cuda:0"):
+        self._lib = _capi.load()
+        if not torch.cuda.is_available():
+            raise _capi.CrenderError("DeviceModel needs a ROCm GPU")
+        self.device = torch.device(device)
+        self._host = model                      # parser / rotate / normals live there
+        self._upload()
+
+    # ------------------------------------------------------------------ plumbing --
+    def _dev(self, a, dtype):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self.device)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _upload(self):
+        m = self._host
+        self._vertices = self._dev(m._vertices, np.float32)
+        self._triangles_vertices = self._dev(m._triangles_vertices, np.int32)
+        self._normals = self._dev(m._normals, np.float32)
+        self._triangles_normals = self._dev(m._triangles_normals, np.int32)
+        if m._colors_by_triangles is not None:
+            self._colors_by_triangles = self._dev(m._colors_by_triangles, np.float32)
+        elif not hasattr(self, "_colors_by_triangles"):
+            self._colors_by_triangles = None          # (colours set on the device model survive a rotate)
+        T = self._triangles_vertices.shape[0]
+        self._vertices_by_triangles = torch.empty((T, 3, 3), dtype=torch.float32, device=self.device)
+        self._normals_by_triangles = torch.empty((T, 3, 3), dtype=torch.float32, device=self.device)
+        self._stats = torch.zeros(4, dtype=torch.float32, device=self.device)   # mean[3], max span
+        self._gather(self._normals, self._triangles_normals, self._normals_by_triangles)
+        self._update()
+
+    def _gather(self, attr, index, out):
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.crender_model_gather(attr.data_ptr(), index.data_ptr(), out.data_ptr(),
+                                                       index.shape[0], self._stream()), "crender_model_gather")
+
+    def _update(self):
+        """model.py:153-160 after a change of the vertices: gather, mean vertex, max span."""
+        self._gather(self._vertices, self._triangles_vertices, self._vertices_by_triangles)
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.crender_model_stats(self._vertices.data_ptr(), self._vertices.shape[0],
+                                                      self._stats.data_ptr(), self._stats.data_ptr() + 12,
+                                                      self._stream()), "crender_model_stats")
+        self._stats_host = None
+
+    def _fetch_stats(self):
+        if self._stats_host is None:
+            self._stats_host = self._stats.cpu().numpy()
+        return self._stats_host
+
+    # ----------------------------------------------------------- reference API --
+    def shift(self, shift):
+        arr = np.asarray(shift)
+        if arr.shape != (3,):
+            arr = np.broadcast_to(arr, (3,))
+        is_f32 = arr.dtype == np.float32 or arr.dtype == np.float16
+        s3 = (C.c_double * 3)(*[float(v) for v in arr])
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.crender_model_shift(self._vertices.data_ptr(), self._vertices.shape[0], s3,
+                                                      1 if is_f32 else 0, self._stream()), "crender_model_shift")
+        self._update()
+
+    def scale(self, scale_coef, keep_position=True):
+        coef = np.float32(scale_coef)            # vtx *= coef is a float32 in-place multiply
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.crender_model_scale(self._vertices.data_ptr(), self._vertices.shape[0],
+                                                      self._stats.data_ptr(), C.c_float(float(coef)),
+                                                      1 if keep_position else 0, self._stream()),
+                        "crender_model_scale")
+        self._update()
+
+    def rotate(self, angles):
+        """Host side (see the module docstring): download, ``Model.rotate``, upload."""
+        m = self._host
+        m._set_geometry(self._vertices.cpu().numpy(), m._triangles_vertices, m._normals,
+                        m._triangles_normals, recalc=False)
+        m.rotate(angles)
+        self._upload()
+
+    def get_mean_vertex(self):
+        return self._fetch_stats()[:3].copy()
+
+    def get_max_span(self):
+        return np.float32(self._fetch_stats()[3])
+
+    def n_triangles(self):
+        return int(self._triangles_vertices.shape[0])
+
+    def n_vertices(self):
+        return int(self._vertices.shape[0])
+
+    def set_uniform_color(self, bgr=(255.0, 255.0, 255.0)):
+        T = self.n_triangles()
+        self._colors_by_triangles = torch.tensor(bgr, dtype=torch.float32, device=self.device) \
+            .expand(T, 3, 3).contiguous()

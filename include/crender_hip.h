@@ -233,6 +233,28 @@ CRENDER_API int crender_guro_illumination(float *d_color, const float *d_normal,
 CRENDER_API int crender_present_u8(const float *d_color, unsigned char *d_out, int H, int W,
                        int flip_rows, void *stream);
 
+/* next row f2: the Model's reproducible transforms on a device-resident
+ * vertex buffer d_vertices = float32 [V][3] — crender/cy/data_structures/model.py:153-236.
+ *   crender_model_shift   Model.shift (:213-216): vertices + shift.  shift_is_float32 = 1: the
+ *                         caller's shift was a float32 array (float32 sum); 0: a Python list / a
+ *                         float64 array (numpy promotes the sum to float64, stored as float32).
+ *   crender_model_scale   Model.scale (:218-236): vtx -= mean; vtx *= coef; vtx += mean in float32
+ *                         (keep_position), or vtx *= coef.  d_mean3: DEVICE pointer to 3 floats.
+ *   crender_model_stats   _update_vertices_and_normals (:153-160): mean vertex (numpy's float32
+ *                         row-after-row sum, float64 division) and max span (max float32 norm of
+ *                         vertices - mean) into DEVICE memory d_mean3 [3], d_max_span [1].
+ *   crender_model_gather  attr[index] (:156, :172, :151): d_attr float32 [N][3], d_index int32
+ *                         [T][3] -> d_out float32 [T][3][3]: the filler's input arrays.
+ * rotate and the vertex-normal computation are not offered: see DESIGN.md. */
+CRENDER_API int crender_model_shift(float *d_vertices, int64_t V, const double *shift3,
+                                    int shift_is_float32, void *stream);
+CRENDER_API int crender_model_scale(float *d_vertices, int64_t V, const float *d_mean3, float coef,
+                                    int keep_position, void *stream);
+CRENDER_API int crender_model_stats(const float *d_vertices, int64_t V, float *d_mean3,
+                                    float *d_max_span, void *stream);
+CRENDER_API int crender_model_gather(const float *d_attr, const int32_t *d_index, float *d_out,
+                                     int64_t T, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -962,3 +962,51 @@ def test_two_ranks_strip_renderer_on_one_gpu(tmp_path):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert f"rank {r} ok" in out
+
+
+def test_device_model_transforms_match_host_model(oracle):
+    """Row f2: shift / scale / mean vertex / max span / the *_by_triangles gathers on the device
+    against the host Model (numpy, the reference's own call sequence) — bit for bit, through the
+    README's fit (shift by a float32 array, scale by 1 / span, shift by a Python list: numpy
+    promotes that sum to float64), a host-side rotate in between, and a render of the result."""
+    from cython3dmodelrenderer_amd.data_structures import DeviceModel, Model
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    from cython3dmodelrenderer_amd.scenes import fit_model
+    rng = np.random.default_rng(11)
+    V, T = 1500, 2600
+    vertices = (rng.standard_normal((V, 3)) * [3.0, 1.0, 0.5] + [10.0, -4.0, 2.0]).astype(np.float32)
+    faces = rng.integers(0, V, (T, 3)).astype(np.int32)
+    host = Model(vertices, faces)
+    host.set_uniform_color()
+    dev = DeviceModel(Model(vertices, faces))
+    dev.set_uniform_color()
+
+    def same(what):
+        assert_bit_equal(dev.get_mean_vertex(), host.get_mean_vertex(), f"{what}: mean vertex")
+        assert np.float32(dev.get_max_span()).view(np.uint32) == np.float32(host.get_max_span()).view(np.uint32), what
+        assert_bit_equal(dev._vertices.cpu().numpy(), host._vertices, f"{what}: vertices")
+        assert_bit_equal(dev._vertices_by_triangles.cpu().numpy(), host._vertices_by_triangles, f"{what}: by triangles")
+        assert_bit_equal(dev._normals_by_triangles.cpu().numpy(), host._normals_by_triangles, f"{what}: normals")
+
+    same("upload")
+    for m in (host, dev):
+        m.rotate([10, -80, 0])
+    same("rotate (host)")
+    for m in (host, dev):
+        fit_model(m)
+    same("fit_model")
+    for m in (host, dev):
+        m.shift(np.array([0.25, -0.125, 3.0]))          # float64 array
+        m.scale(0.37, keep_position=False)
+        m.shift(np.float32(0.5) * np.ones(3, np.float32))
+    same("more transforms")
+    for m in (host, dev):
+        fit_model(m)
+    same("fit again")
+    # and the filler takes the device arrays as they are
+    f = oracle.OracleFiller(200, 200, fov=45)
+    f.render_model(host)
+    filler = AdvancedPixelBufferFiller(200, 200, fov=45)
+    filler.render_model(dev)
+    assert_bit_equal(filler.get_z_buffer(), f.z_buffer, "render of the device model: z")
+    assert_bit_equal(filler.get_color_buffer(), f.color_buffer, "render of the device model: colour")
