@@ -1086,6 +1086,11 @@ struct TileLists {
     const float4 *bins;         // direct bins: [ntiles][capacity] entries (BinEntry, three pieces each)
     uint32_t capacity;
     uint32_t T;                 // triangle count: list entries >= T (stale workspace) are ignored
+    // The triangle arrays may be a PERMUTATION of the caller's (crender_plan_set_triangle_order:
+    // tile-coherent order, so that list entries and winners gather near-streams).  Depth keys and
+    // the winner plane speak the caller's indices: orig_of[position] for the key, pos_of[index]
+    // back to the arrays.  Both null: the arrays are in the caller's order.
+    const uint32_t *orig_of, *pos_of;
     // heavy tiles (see register_heavy): null / 0 when the launch has no helper workgroups
     uint32_t *heavy_flag, *heavy_slots, *heavy_ctr_next;
     int nhelp;                  // 3 * hmax helper workgroups
@@ -1390,6 +1395,7 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
     TriXYZ cur_t{};
     bool cur_ok = tid < kBatch && beg + tid < end;
     if (cur_ok) cur_ok = load_record(L, proj, G, beg + tid, cur_id, cur_t, cur_bx, cur_by);
+    if (cur_ok && L.orig_of) cur_id = L.orig_of[cur_id];      // from here on: the caller's index
 
     // depth keys of the tile: the prior buffer value (or the cleared value) per pixel
     const unsigned long long key_clear = make_key(zord(1e6f), KEY_LOW_PRIOR);
@@ -1509,6 +1515,7 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
         const uint32_t nxt = base + kBatch + tid;
         cur_ok = tid < kBatch && nxt < end;
         if (cur_ok) cur_ok = load_record(L, proj, G, nxt, cur_id, cur_t, cur_bx, cur_by);
+        if (cur_ok && L.orig_of) cur_id = L.orig_of[cur_id];
 
         // ---- sweep: the batch's work items, flattened and split evenly -------------------------
         {
@@ -1731,7 +1738,8 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
             id = 0xFFFFu - (low >> 16);
             if (((low >> 8) & 0xFFu) == (((end - beg - 1) / kBatch) & 0xFFu) && !(dbg & 2)) {
                 // the winner's record is still in LDS (it came with the last batch)
-                shade16_store(load_rec16(&recs[low & 0xFFu]), col, nrm, id, x, y, pix, zb, cb, nb, L.light);
+                shade16_store(load_rec16(&recs[low & 0xFFu]), col, nrm, L.pos_of ? L.pos_of[id] : id, x, y, pix,
+                              zb, cb, nb, L.light);
                 if (win) win[pix] = (int32_t)id;
                 continue;
             }
@@ -1742,7 +1750,7 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
             nb[pix * 3] = 1.0f; nb[pix * 3 + 1] = 1.0f; nb[pix * 3 + 2] = 1.0f;
             continue;
         }
-        shade_and_store(proj, col, nrm, id, x, y, pix, zb, cb, nb, L.light);
+        shade_and_store(proj, col, nrm, L.pos_of ? L.pos_of[id] : id, x, y, pix, zb, cb, nb, L.light);
         if (win) win[pix] = (int32_t)id;
     }
     CR_STAMP(3);
@@ -1965,6 +1973,29 @@ __global__ __launch_bounds__(kThreads) void k_model_gather(const float *__restri
     }
 }
 
+// Sort key of a triangle for the tile-coherent order: Morton code of the 32-pixel tile its
+// projected centroid falls in (an ordering heuristic only: nothing exact depends on it).
+__global__ __launch_bounds__(kThreads) void k_tile_order_keys(const float *__restrict__ tri, int64_t T,
+                                                              ProjConst P, int W, int H,
+                                                              uint32_t *__restrict__ keys)
+{
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < T; t += stride) {
+        const float *v = tri + t * 9;
+        float c[3] = {(v[0] + v[3] + v[6]) * (1.0f / 3.0f), (v[1] + v[4] + v[7]) * (1.0f / 3.0f),
+                      (v[2] + v[5] + v[8]) * (1.0f / 3.0f)};
+        project_vertex(P, c);
+        int x = (int)c[0], y = (int)c[1];
+        x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+        y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+        if (!(c[0] == c[0]) || !(c[1] == c[1])) x = y = 0;
+        uint32_t a = (uint32_t)x >> 5, b = (uint32_t)y >> 5, m = 0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) m |= ((a >> k) & 1u) << (2 * k) | ((b >> k) & 1u) << (2 * k + 1);
+        keys[t] = m;
+    }
+}
+
 // ---- host side --------------------------------------------------------------------
 constexpr size_t kAlign = 256;
 size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
@@ -2074,6 +2105,7 @@ struct crender_plan {
     uint32_t *hslots() const { return reinterpret_cast<uint32_t *>(ws + L.off_hslots); }
     int hint_par = 0;             // order / hint buffer the next raster launch reads (it writes the other)
     float light[3] = {0.f, 0.f, 0.f};   // crender_plan_set_light (CRENDER_FUSED_GURO)
+    const uint32_t *orig_of = nullptr, *pos_of = nullptr;   // crender_plan_set_triangle_order
     bool frame_lone = true;       // the last bin pass belonged to a frame rendered for latency (no
                                   // CRENDER_OVERLAPPED_FRAMES): ordered dispatch and split heavy tiles
     uint32_t *hint(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_hint) + 4 * k; }
@@ -2267,6 +2299,8 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     tl.bins = plan->direct();
     tl.capacity = direct ? (uint32_t)L.direct_cap : (uint32_t)L.capacity;
     tl.T = (uint32_t)plan->last_T;
+    tl.orig_of = plan->orig_of;
+    tl.pos_of = plan->pos_of;
     const bool split = direct && L.hmax > 0 && plan->frame_lone && !(dbg & 2048);
     tl.heavy_flag = split ? plan->hflag() : nullptr;
     tl.heavy_slots = split ? plan->hslots() : nullptr;
@@ -2519,6 +2553,15 @@ int crender_plan_last_bin_usage(crender_plan *plan, void *stream, int64_t *neede
     return CRENDER_OK;
 }
 
+int crender_plan_set_triangle_order(crender_plan *plan, const uint32_t *d_orig_of, const uint32_t *d_pos_of)
+{
+    if (!plan || ((d_orig_of == nullptr) != (d_pos_of == nullptr)))
+        return fail(CRENDER_EINVAL, "crender_plan_set_triangle_order: both arrays or neither");
+    plan->orig_of = d_orig_of;
+    plan->pos_of = d_pos_of;
+    return CRENDER_OK;
+}
+
 int crender_plan_set_light(crender_plan *plan, const float *light3)
 {
     if (!plan || !light3) return fail(CRENDER_EINVAL, "crender_plan_set_light: bad argument");
@@ -2757,6 +2800,18 @@ int crender_guro_illumination(float *d_color, const float *d_normal, const float
                        static_cast<hipStream_t>(stream), d_color, d_normal, light3[0], light3[1],
                        light3[2], first, npix);
     CR_LAUNCH_CHECK("k_guro");
+    return CRENDER_OK;
+}
+
+int crender_tile_order_keys(const float *d_tri, int64_t T, const float *P16, int w, int h, uint32_t *d_keys,
+                            void *stream)
+{
+    if (T < 0 || !P16 || w <= 0 || h <= 0 || (T > 0 && (!d_tri || !d_keys)))
+        return fail(CRENDER_EINVAL, "crender_tile_order_keys: bad argument");
+    if (T == 0) return CRENDER_OK;
+    hipLaunchKernelGGL(k_tile_order_keys, dim3(grid_for((size_t)T, 4096)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), d_tri, T, make_proj(P16, w, h), w, h, d_keys);
+    CR_LAUNCH_CHECK("k_tile_order_keys");
     return CRENDER_OK;
 }
 

@@ -125,6 +125,20 @@ CRENDER_API int crender_plan_last_bin_usage(crender_plan *plan, void *stream,
 
 CRENDER_API int crender_plan_last_frame_direct(crender_plan *plan);
 
+/* Tile-coherent triangle order (no reference counterpart: a data-layout choice for scenes of
+ * millions of small triangles, where gathering unsorted 36-byte records dominates the frame).
+ * The caller may hand the kernels a PERMUTATION of its triangle arrays (all three alike), sorted
+ * so that triangles of one screen region are neighbours in memory — crender_tile_order_keys
+ * writes a sort key per triangle (Morton code of the 32-pixel tile of its projected centroid) —
+ * and tell the plan about it: d_orig_of[position] = index in the caller's own arrays,
+ * d_pos_of[index] = position (uint32 [T] each, device memory that outlives the plan's frames;
+ * NULL, NULL = no permutation).  Results are unchanged: depth ties still go to the highest index
+ * of the caller's arrays and the winner plane reports those indices. */
+CRENDER_API int crender_tile_order_keys(const float *d_tri, int64_t T, const float *P16, int w, int h,
+                                        uint32_t *d_keys, void *stream);
+CRENDER_API int crender_plan_set_triangle_order(crender_plan *plan, const uint32_t *d_orig_of,
+                                                const uint32_t *d_pos_of);
+
 /* Light direction (host pointer to 3 floats, copied) for frames rendered with CRENDER_FUSED_GURO:
  * GuroIllumination.__init__'s light_direction (guro_illumination.py:6-18). */
 CRENDER_API int crender_plan_set_light(crender_plan *plan, const float *light3);

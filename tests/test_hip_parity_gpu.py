@@ -1010,3 +1010,29 @@ def test_device_model_transforms_match_host_model(oracle):
     filler.render_model(dev)
     assert_bit_equal(filler.get_z_buffer(), f.z_buffer, "render of the device model: z")
     assert_bit_equal(filler.get_color_buffer(), f.color_buffer, "render of the device model: colour")
+
+
+@pytest.mark.parametrize("T,res,tile", [(300_000, 1024, 0), (300_000, 2048, 0), (40_000, 512, 0)])
+def test_tile_coherent_order_changes_nothing(oracle, T, res, tile):
+    """Large models are kept in HBM sorted by screen tile (crender_plan_set_triangle_order); depth
+    ties and the winner plane still speak the caller's triangle indices.  Small random triangles
+    with many exact ties (coordinates snapped to a coarse grid), sorted vs unsorted vs oracle, on
+    the plain and the pipelined path."""
+    from cython3dmodelrenderer_amd import scenes
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    tri, col, nrm = scenes.synthetic_triangles(T, res=res, seed=77)
+    tri = (np.round(tri * 512) / 512).astype(np.float32)          # shared edges and equal depths
+    f = oracle.OracleFiller(res, res, fov=45)
+    f.render_arrays(tri, col, nrm)
+    for presort in (True, False):
+        filler = AdvancedPixelBufferFiller(res, res, fov=45, tile=tile, presort=presort, track_winner=True,
+                                           pipeline=True)
+        filler.render_arrays(tri, col, nrm, clear=True)
+        assert (filler._order is not None) == presort
+        for burst in (0, 4):
+            for _ in range(burst):
+                filler.render_frame()
+            assert_bit_equal(filler.get_z_buffer(), f.z_buffer, f"presort={presort}: z")
+            assert_bit_equal(filler.get_color_buffer(), f.color_buffer, f"presort={presort}: colour")
+            assert_bit_equal(filler.get_normals_buffer(), f.normals_buffer, f"presort={presort}: normal")
+            assert_bit_equal(filler.get_winner_tensor().cpu().numpy(), f.winner, f"presort={presort}: winner")
