@@ -67,6 +67,8 @@ def load():
     spec = importlib.util.spec_from_file_location(NAME, so)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    if mod.abi_version() != _capi.ABI_VERSION:
+        raise ImportError(f"{NAME} is bound to ABI {mod.abi_version()}, this package speaks {_capi.ABI_VERSION}: rebuild")
     sys.modules.setdefault(NAME, mod)
     _mod = mod
     return mod

@@ -23,7 +23,7 @@
 // there CRENDER_DEBUG (environment, read once) is a bit mask; the product library is compiled
 // without them (every `dbg & bit` below folds to 0):
 //   1 no coverage work, 2 no shading (both produce WRONG images: ablation timing only),
-//   8 XCD-banded tile map, 16 never use direct bins, 32 no sign rejection, 64 no hoisted
+//   4 block-histogram count / fill passes on every scan-path frame, 8 XCD-banded tile map, 16 never use direct bins, 32 no sign rejection, 64 no hoisted
 //   reciprocal, 128 small-record block sweep for every batch (64-pixel tiles), 256 invert the
 //   scatter-dispatch rule, 512 no row rotation of the tile map, 4096 coarse pass keeps every
 //   block, 8192 large-record sweep for every batch (32/64-pixel tiles), bits 16..23 = n + 1:
@@ -662,6 +662,139 @@ __global__ __launch_bounds__(kWave) void k_setup_wave(const float *__restrict__ 
         if (slot < dcap) put_entry<NP>(bins + ((size_t)(ty * G.ntx + tx) * dcap + slot) * NP, img, owner);
     });
     CR_SETUP_STAMP(5);      // entries issued
+}
+
+// ---- scan path, one wavefront per 64 triangles ------------------------------------------------
+// The count and fill passes of the scan path in the shape of k_setup_wave: no block-wide histogram
+// (k_setup's 32 KB + 18 KB of LDS hold a CU to three workgroups whose loads, arithmetic and stores
+// take turns: 3.2 TB/s on 10 M triangles), ceil(T / 64) independent wavefronts instead, a few KB of
+// LDS each, so that a CU always has loads of some of them in flight.  List lengths are aggregated
+// per wavefront over its tile bounding box — neighbouring triangles of a mesh, or of a model kept
+// in tile-coherent order, share their tiles — and cost one global atomic per touched tile; a
+// wavefront whose box exceeds the histogram counts pair by pair.
+template <int TS, bool PROJECT>
+__global__ __launch_bounds__(kWave) void k_count_wave(const float *__restrict__ tri_in,
+                                                      const float *__restrict__ nrm,
+                                                      float *__restrict__ proj_out,
+                                                      uint2 *__restrict__ trange,
+                                                      uint32_t *__restrict__ count, int64_t T,
+                                                      ProjConst P, Geom G)
+{
+    __shared__ __attribute__((aligned(16))) float sv[kWave * 9];
+    __shared__ uint32_t hist[kWaveHistTiles];
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    const int n = (int)((T - b0) < kWave ? (T - b0) : kWave);
+    stage_in<kWave>(tri_in + b0 * 9, sv, n * 9);
+    float nz0 = 0.0f, nz1 = 0.0f, nz2 = 0.0f;      // .pyx:202 looks at the normals' z only
+    if (lane < n) {
+        const float *nn = nrm + (b0 + lane) * 9;
+        nz0 = nn[2]; nz1 = nn[5]; nz2 = nn[8];
+    }
+    __syncthreads();
+    uint2 r = make_uint2(kNoTiles, 0);
+    if (lane < n) {
+        float *v = sv + lane * 9;
+        float a[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a[i] = v[i];
+        if (PROJECT) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) project_vertex(P, a + 3 * c);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) v[i] = a[i];
+        }
+        const TriXYZ t{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]};
+        if (!backface(nz0, nz1, nz2)) r = tile_range<TS>(t, G);
+        trange[b0 + lane] = r;
+    }
+    int X0 = 0x7FFFFFFF, X1 = -1, Y0 = 0x7FFFFFFF, Y1 = -1;
+    if (r.x != kNoTiles) {
+        X0 = r.x & 0xFFFF; X1 = r.x >> 16; Y0 = r.y & 0xFFFF; Y1 = r.y >> 16;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        X0 = min(X0, __shfl_xor(X0, d, 64)); X1 = max(X1, __shfl_xor(X1, d, 64));
+        Y0 = min(Y0, __shfl_xor(Y0, d, 64)); Y1 = max(Y1, __shfl_xor(Y1, d, 64));
+    }
+    __syncthreads();
+    if (PROJECT) stage_out<kWave>(proj_out + b0 * 9, sv, n * 9);
+    if (X1 < 0) return;     // nothing to count (uniform)
+    const int bw = X1 - X0 + 1, area = bw * (Y1 - Y0 + 1);
+    if (area > kWaveHistTiles) {
+        for_each_tile(r, 0u, G.ntx, [&](int tile, uint32_t) { atomicAdd(&count[tile], 1u); });
+        return;
+    }
+    for (int i = lane; i < area; i += kWave) hist[i] = 0;
+    __syncthreads();
+    for_each_tile_xy(r, [&](int tx, int ty, int) { atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u); });
+    __syncthreads();
+    const float rbw = 1.0f / (float)bw;
+    for (int i = lane; i < area; i += kWave) {
+        const uint32_t c = hist[i];
+        const int dy = (int)(((float)i + 0.5f) * rbw);              // exact: i < 2^22
+        if (c) atomicAdd(&count[(Y0 + dy) * G.ntx + X0 + (i - dy * bw)], c);
+    }
+}
+
+// The fill pass in the same shape: (A) the wavefront's entries per tile in LDS, (B) one returning
+// atomic per touched tile on the list's cursor reserves a run, (C) LDS cursors hand out its slots.
+// trange is read once (k_fill's block histograms need two sweeps).
+__global__ __launch_bounds__(kWave) void k_fill_wave(const uint2 *__restrict__ trange,
+                                                     const uint32_t *__restrict__ offs,
+                                                     uint32_t *__restrict__ cursor,
+                                                     uint32_t *__restrict__ entries,
+                                                     uint32_t capacity, int64_t T, Geom G)
+{
+    __shared__ uint32_t hist[kWaveHistTiles];
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    uint2 r = (b0 + lane < T) ? trange[b0 + lane] : make_uint2(kNoTiles, 0);
+    int X0 = 0x7FFFFFFF, X1 = -1, Y0 = 0x7FFFFFFF, Y1 = -1;
+    if (r.x != kNoTiles) {
+        X0 = r.x & 0xFFFF; X1 = r.x >> 16; Y0 = r.y & 0xFFFF; Y1 = r.y >> 16;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        X0 = min(X0, __shfl_xor(X0, d, 64)); X1 = max(X1, __shfl_xor(X1, d, 64));
+        Y0 = min(Y0, __shfl_xor(Y0, d, 64)); Y1 = max(Y1, __shfl_xor(Y1, d, 64));
+    }
+    if (X1 < 0) return;
+    const int bw = X1 - X0 + 1, area = bw * (Y1 - Y0 + 1);
+    if (area > kWaveHistTiles) {
+        for_each_tile(r, (uint32_t)(b0 + lane), G.ntx, [&](int tile, uint32_t id) {
+            const uint32_t pos = offs[tile] + atomicAdd(&cursor[tile], 1u);
+            if (pos < capacity) entries[pos] = id;
+        });
+        return;
+    }
+    for (int i = lane; i < area; i += kWave) hist[i] = 0;
+    __syncthreads();
+    for_each_tile_xy(r, [&](int tx, int ty, int) { atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u); });
+    __syncthreads();
+    {
+        constexpr int kRounds = kWaveHistTiles / kWave;
+        const float rbw = 1.0f / (float)bw;
+        uint32_t c[kRounds], t[kRounds], base[kRounds];
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            const int i = k * kWave + lane;
+            c[k] = (k * kWave < area && i < area) ? hist[i] : 0u;
+            const int dy = (int)(((float)i + 0.5f) * rbw);          // exact: i < 2^22
+            t[k] = (uint32_t)((Y0 + dy) * G.ntx + X0 + (i - dy * bw));
+        }
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k)                            // all in flight together
+            base[k] = c[k] ? offs[t[k]] + atomicAdd(&cursor[t[k]], c[k]) : 0u;
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k)
+            if (c[k]) hist[k * kWave + lane] = base[k];
+    }
+    __syncthreads();
+    for_each_tile_xy(r, [&](int tx, int ty, int owner) {
+        const uint32_t pos = atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u);
+        if (pos < capacity) entries[pos] = (uint32_t)(b0 + owner);
+    });
 }
 
 // Exclusive scan of count[0..ntiles) into offs[0..ntiles]; count is zeroed (k_fill uses
@@ -2162,6 +2295,7 @@ int grid_for(size_t items, int cap)
 // LDS histograms up to this many tiles: k_setup packs 16-bit counters (32 KiB + 18 KiB of
 // staging), k_fill needs 32-bit cursors (64 KiB, the dynamic-LDS limit is raised for it).
 constexpr int kMaxLdsHistTiles = 16384;
+constexpr int64_t kWaveScanBelow = 1 << 18;   // (the filler keeps larger models tile-coherent)
 
 // Frame = bin pass (K1 + binning into the plan) + raster pass (K2 from the plan's bins).
 int dev_knobs()
@@ -2209,6 +2343,10 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
     // block-private LDS histograms pay off when a block's chunk is dense in tiles; a small
     // scene on a large tile grid would only zero and flush mostly empty histograms
     const bool lds_hist = G.ntiles <= 4096 || (G.ntiles <= kMaxLdsHistTiles && T >= 16 * (int64_t)G.ntiles);
+    // Scan path: one wavefront per 64 triangles (k_count_wave / k_fill_wave) where neighbouring
+    // triangles can be expected to share tiles — a mesh, or a large model kept in tile-coherent
+    // order; a large triangle soup in arbitrary order keeps the block histograms.
+    const bool wave_scan = (plan->orig_of != nullptr || T < kWaveScanBelow) && !(dbg & 4);
     if (T > 0 && direct) {
         // direct bins: one wavefront per 64 triangles
         HeavyReg hv;
@@ -2230,6 +2368,15 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
                                plan->proj(), count, plan->direct(), (uint32_t)L.direct_cap, plan->hdr(),
                                hv, T, P, G);
         CR_LAUNCH_CHECK("k_setup_wave");
+    } else if (T > 0 && wave_scan) {
+        const unsigned nwg = (unsigned)((T + kWave - 1) / kWave);
+        if (project)
+            hipLaunchKernelGGL((k_count_wave<TS, true>), dim3(nwg), dim3(kWave), 0, s, d_tri, d_nrm,
+                               plan->proj(), plan->trange(), count, T, P, G);
+        else
+            hipLaunchKernelGGL((k_count_wave<TS, false>), dim3(nwg), dim3(kWave), 0, s, d_tri, d_nrm,
+                               plan->proj(), plan->trange(), count, T, P, G);
+        CR_LAUNCH_CHECK("k_count_wave");
     } else if (T > 0) {
         int64_t nblk, chunk;
         chunking(2048, nblk, chunk);
@@ -2261,13 +2408,17 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
             int64_t nblk, chunk;
             chunking(1024, nblk, chunk);
             const size_t lds = lds_hist ? sizeof(uint32_t) * (size_t)G.ntiles : 0;
-            if (lds_hist && lds > 48 * 1024) {
+            if (!wave_scan && lds_hist && lds > 48 * 1024) {
                 static const hipError_t attr = hipFuncSetAttribute(
                     reinterpret_cast<const void *>(&k_fill<true>),
                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
                 if (attr != hipSuccess) return fail_hip(attr, "hipFuncSetAttribute(k_fill)");
             }
-            if (lds_hist)
+            if (wave_scan)
+                hipLaunchKernelGGL(k_fill_wave, dim3((unsigned)((T + kWave - 1) / kWave)), dim3(kWave), 0, s,
+                                   plan->trange(), plan->offs(), count, plan->entries(),
+                                   (uint32_t)L.capacity, T, G);
+            else if (lds_hist)
                 hipLaunchKernelGGL((k_fill<true>), dim3((unsigned)nblk), dim3(kThreads), lds, s,
                                    plan->trange(), plan->offs(), count, plan->entries(),
                                    (uint32_t)L.capacity, T, chunk, G);
