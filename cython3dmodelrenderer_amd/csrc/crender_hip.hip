@@ -2106,6 +2106,31 @@ __global__ __launch_bounds__(kThreads) void k_model_gather(const float *__restri
     }
 }
 
+// Row f4's device part — model.py:143-151: one colour per texture coordinate, the nearest texel
+// with the v axis flipped, as float32:
+//   row = clip(int32((1 - v) * h), 0, h - 1), column = clip(int32(u * w), 0, w - 1)
+// in numpy's float32 arithmetic; the cast is the host's truncating conversion, which yields
+// INT_MIN (so, after the clip, texel 0) for a NaN and for anything outside int32.
+CR_DEV int host_f32_to_i32(float f)
+{
+    return (f >= -2147483648.0f && f < 2147483648.0f) ? (int)f : (int)0x80000000;
+}
+__global__ __launch_bounds__(kThreads) void k_model_texture_colors(const float *__restrict__ uv, int uv_cols,
+                                                                   int64_t n, const unsigned char *__restrict__ tex,
+                                                                   int th, int tw, float *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const float u = uv[i * uv_cols], v = uv[i * uv_cols + 1];
+        int row = host_f32_to_i32((1.0f - v) * (float)th);
+        int colm = host_f32_to_i32(u * (float)tw);
+        row = row < 0 ? 0 : (row > th - 1 ? th - 1 : row);
+        colm = colm < 0 ? 0 : (colm > tw - 1 ? tw - 1 : colm);
+        const unsigned char *t = tex + ((size_t)row * tw + colm) * 3;
+        out[i * 3] = (float)t[0]; out[i * 3 + 1] = (float)t[1]; out[i * 3 + 2] = (float)t[2];
+    }
+}
+
 // Sort key of a triangle for the tile-coherent order: Morton code of the 32-pixel tile its
 // projected centroid falls in (an ordering heuristic only: nothing exact depends on it).
 __global__ __launch_bounds__(kThreads) void k_tile_order_keys(const float *__restrict__ tri, int64_t T,
@@ -3001,6 +3026,19 @@ int crender_model_stats(const float *d_vertices, int64_t V, float *d_mean3, floa
     hipLaunchKernelGGL(k_model_max_span, dim3(grid_for((size_t)V, 1024)), dim3(kThreads), 0, s, d_vertices, V,
                        d_mean3, reinterpret_cast<uint32_t *>(d_max_span));
     CR_LAUNCH_CHECK("k_model_max_span");
+    return CRENDER_OK;
+}
+
+int crender_model_texture_colors(const float *d_uv, int uv_cols, int64_t n, const unsigned char *d_texture,
+                                 int th, int tw, float *d_out, void *stream)
+{
+    if (n < 0 || uv_cols < 2 || th <= 0 || tw <= 0 || th > (1 << 24) || tw > (1 << 24) ||
+        (n > 0 && (!d_uv || !d_texture || !d_out)))
+        return fail(CRENDER_EINVAL, "crender_model_texture_colors: bad argument");
+    if (n == 0) return CRENDER_OK;
+    hipLaunchKernelGGL(k_model_texture_colors, dim3(grid_for((size_t)n, 4096)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), d_uv, uv_cols, n, d_texture, th, tw, d_out);
+    CR_LAUNCH_CHECK("k_model_texture_colors");
     return CRENDER_OK;
 }
 

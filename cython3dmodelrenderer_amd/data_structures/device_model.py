@@ -2,7 +2,8 @@
 (crender/cy/data_structures/model.py:118-256) with its vertex, index and normal arrays kept in HBM
 and the transforms that are exactly reproducible there running as HIP kernels:
 
-    shift, scale, the mean vertex, the max span, and the three ``*_by_triangles`` gathers
+    shift, scale, the mean vertex, the max span, the three ``*_by_triangles`` gathers, and (row f4)
+    the per-texture-coordinate colour lookup of a textured model (model.py:143-151)
 
 each in numpy's own operation order (float32 elementwise; float64 where numpy promotes; the mean
 as numpy's row-after-row float32 sum), so the arrays handed to the filler are, bit for bit, what
@@ -37,16 +38,26 @@ class DeviceModel:
     def _dev(self, a, dtype):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self.device)
 
+    def _dev_index(self, idx, n):
+        """Face indices as the gather kernel takes them: numpy's fancy indexing counts a negative
+        index (an .obj file's relative reference, model.py:276-279) from the end."""
+        idx = np.asarray(idx, dtype=np.int64)
+        if idx.size and (idx.min() < -n or idx.max() >= n):
+            raise IndexError(f"index out of bounds for axis 0 with size {n}")
+        return self._dev(np.where(idx < 0, idx + n, idx), np.int32)
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _upload(self):
         m = self._host
         self._vertices = self._dev(m._vertices, np.float32)
-        self._triangles_vertices = self._dev(m._triangles_vertices, np.int32)
+        self._triangles_vertices = self._dev_index(m._triangles_vertices, len(m._vertices))
         self._normals = self._dev(m._normals, np.float32)
-        self._triangles_normals = self._dev(m._triangles_normals, np.int32)
-        if m._colors_by_triangles is not None:
+        self._triangles_normals = self._dev_index(m._triangles_normals, len(m._normals))
+        if m._texture is not None:
+            self._sample_texture(m)
+        elif m._colors_by_triangles is not None:
             self._colors_by_triangles = self._dev(m._colors_by_triangles, np.float32)
         elif not hasattr(self, "_colors_by_triangles"):
             self._colors_by_triangles = None          # (colours set on the device model survive a rotate)
@@ -56,6 +67,21 @@ class DeviceModel:
         self._stats = torch.zeros(4, dtype=torch.float32, device=self.device)   # mean[3], max span
         self._gather(self._normals, self._triangles_normals, self._normals_by_triangles)
         self._update()
+
+    def _sample_texture(self, m):
+        """model.py:143-151 on the device: texture (uint8 BGR), texture coordinates and the faces'
+        texture indices go up as they were parsed; colours and colours-by-triangles are made there."""
+        uv = self._dev(m._texture_coords, np.float32)
+        tex = torch.from_numpy(np.ascontiguousarray(m._texture[:, :, :3], dtype=np.uint8)).to(self.device)
+        th, tw = int(tex.shape[0]), int(tex.shape[1])
+        self._colors = torch.empty((uv.shape[0], 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.crender_model_texture_colors(uv.data_ptr(), int(uv.shape[1]), uv.shape[0],
+                                                               tex.data_ptr(), th, tw, self._colors.data_ptr(),
+                                                               self._stream()), "crender_model_texture_colors")
+        idx = self._dev_index(m._triangles_texture_coords, uv.shape[0])
+        self._colors_by_triangles = torch.empty((idx.shape[0], 3, 3), dtype=torch.float32, device=self.device)
+        self._gather(self._colors, idx, self._colors_by_triangles)
 
     def _gather(self, attr, index, out):
         with torch.cuda.device(self.device):

@@ -259,6 +259,12 @@ CRENDER_API int crender_present_u8(const float *d_color, unsigned char *d_out, i
  *                         vertices - mean) into DEVICE memory d_mean3 [3], d_max_span [1].
  *   crender_model_gather  attr[index] (:156, :172, :151): d_attr float32 [N][3], d_index int32
  *                         [T][3] -> d_out float32 [T][3][3]: the filler's input arrays.
+ *   crender_model_texture_colors  next row f4, its device part (:143-151): one float32 BGR
+ *                         colour per texture coordinate — nearest texel, v axis flipped, numpy's
+ *                         float32 arithmetic and truncating int32 cast.  d_uv float32 [n][uv_cols]
+ *                         (u, v first; uv_cols >= 2), d_texture uint8 [th][tw][3] -> d_out float32
+ *                         [n][3]; crender_model_gather with the faces' texture indices then gives
+ *                         colors_by_triangles.  (Parsing .obj / .mtl text stays on the host.)
  * rotate and the vertex-normal computation are not offered: see DESIGN.md. */
 CRENDER_API int crender_model_shift(float *d_vertices, int64_t V, const double *shift3,
                                     int shift_is_float32, void *stream);
@@ -268,6 +274,9 @@ CRENDER_API int crender_model_stats(const float *d_vertices, int64_t V, float *d
                                     float *d_max_span, void *stream);
 CRENDER_API int crender_model_gather(const float *d_attr, const int32_t *d_index, float *d_out,
                                      int64_t T, void *stream);
+CRENDER_API int crender_model_texture_colors(const float *d_uv, int uv_cols, int64_t n,
+                                             const unsigned char *d_texture, int th, int tw,
+                                             float *d_out, void *stream);
 
 #ifdef __cplusplus
 }

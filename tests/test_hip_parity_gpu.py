@@ -1012,6 +1012,34 @@ def test_device_model_transforms_match_host_model(oracle):
     assert_bit_equal(filler.get_color_buffer(), f.color_buffer, "render of the device model: colour")
 
 
+def test_device_model_texture_colors_match_host_model():
+    """Row f4's device part: the per-texture-coordinate colour lookup (reference model.py:143-151:
+    nearest texel, v flipped, numpy's float32 arithmetic and truncating int32 cast) and the
+    colours-by-triangles gather on the device against the host Model, bit for bit — texture
+    coordinates inside, on the edges, outside [0, 1], huge, infinite and NaN, two and three columns,
+    and faces that use an .obj file's negative (relative) indices."""
+    from cython3dmodelrenderer_amd.data_structures import DeviceModel, Model
+    rng = np.random.default_rng(23)
+    V, T, N = 400, 700, 900
+    vertices = rng.standard_normal((V, 3)).astype(np.float32)
+    faces = rng.integers(-V, V, (T, 3)).astype(np.int32)
+    for cols, (th, tw) in ((2, (37, 53)), (3, (128, 64)), (2, (1, 1))):
+        texture = rng.integers(0, 256, (th, tw, 3)).astype(np.uint8)
+        uv = rng.uniform(-0.25, 1.25, (N, cols)).astype(np.float32)
+        uv[:40, :2] = rng.integers(0, 2, (40, 2))                                   # exactly 0 and 1
+        uv[40:60, :2] = np.float32(1.0) - np.float32(2.0) ** -rng.integers(1, 25, (20, 2))
+        uv[60:70, :2] = [[np.nan, 0.5], [0.5, np.nan], [np.inf, 0.5], [0.5, -np.inf], [3e9, 0.5],
+                         [0.5, -3e9], [1e38, 1e38], [-1e38, -1e38], [2.0 ** 31 / tw, 0.5], [0.5, 1 - 2.0 ** 31 / th]]
+        faces_t = rng.integers(-N, N, (T, 3)).astype(np.int32)
+        with np.errstate(invalid="ignore", over="ignore"):
+            host = Model(vertices, faces, uv.tolist(), faces_t, texture)
+        dev = DeviceModel(host)
+        assert_bit_equal(dev._colors.cpu().numpy(), host._colors, f"{cols} columns, {th}x{tw}: colours")
+        assert_bit_equal(dev._colors_by_triangles.cpu().numpy(), host._colors_by_triangles,
+                         f"{cols} columns, {th}x{tw}: colours by triangles")
+        assert_bit_equal(dev._vertices_by_triangles.cpu().numpy(), host._vertices_by_triangles, "negative face indices")
+
+
 @pytest.mark.parametrize("T,res,tile", [(300_000, 1024, 0), (300_000, 2048, 0), (40_000, 512, 0)])
 def test_tile_coherent_order_changes_nothing(oracle, T, res, tile):
     """Large models are kept in HBM sorted by screen tile (crender_plan_set_triangle_order); depth
