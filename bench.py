@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
     ap.add_argument("--pipeline-depth", type=int, default=0,
                     help="frames in flight (swap-chain depth); 0 = the filler's choice")
+    ap.add_argument("--lookahead", default="auto", choices=["auto", "on", "off"],
+                    help="swap chain: one launch per frame, the raster pass together with the binning pass of "
+                         "the slot's next frame (auto: scenes that fit the direct bins)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1: 'nccl' (= RCCL, one rank per GPU).  'gloo' is a rehearsal of the "
                          "launch contract on a box with fewer GPUs than ranks: ranks share devices "
@@ -182,7 +185,8 @@ def main():
         sr = None
         filler = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile,
                                            pipeline=not args.no_pipeline,
-                                           pipeline_depth=args.pipeline_depth)
+                                           pipeline_depth=args.pipeline_depth,
+                                           lookahead={"auto": None, "on": True, "off": False}[args.lookahead])
 
     def step(pipelined=True, gather=True):
         if sr is not None:
@@ -305,7 +309,12 @@ def main():
                        "pipelined": (False if args.no_pipeline else
                                      f"swap chain of {filler._pipeline_depth} (GPU_MAX_HW_QUEUES="
                                      f"{os.environ.get('GPU_MAX_HW_QUEUES')}): frames in flight render into "
-                                     "separate framebuffer sets on separate streams, each frame complete"),
+                                     "separate framebuffer sets on separate streams, each frame complete"
+                                     + ("; one launch per frame: its raster pass and, in the same launch, the "
+                                        "binning pass of the stream's next frame (every frame is binned exactly "
+                                        "once; the first frame of a stream after a synchronisation bins in a "
+                                        "launch of its own)"
+                                        if filler._pipe is not None and filler._pipe.lookahead else "")),
                        "all_gather": bool(strips and not args.no_gather)},
             "mtris_per_sec": T * fps / 1e6,
             "frame_algorithmic_bytes": algorithmic_bytes(T, H, W),

@@ -527,21 +527,45 @@ CR_DEV void bin_direct_append(uint2 r_keep, const float4 *img, int ntx,
 // A wavefront whose box exceeds the histogram (large triangles) appends pair by pair.
 constexpr int kWave = 64;
 constexpr int kWaveHistTiles = 512;       // 8 rounds of 64 lanes in pass B
+// (the body is a function of its own — one wavefront, lanes = threads 0..63 of the workgroup, LDS
+// handed in — so that k_frame can run it beside a raster launch's workgroups)
+struct SetupArgs {
+    const float *tri_in, *nrm;
+    float *proj_out;
+    uint32_t *count;
+    float4 *bins;
+    uint32_t dcap;
+    uint32_t *hdr;
+    HeavyReg hv;
+    int64_t T;
+    ProjConst P;
+    Geom G;
+};
+constexpr size_t kSetupWaveLds = sizeof(float) * kWave * 9 + sizeof(float4) * kWave * kEntryPieces +
+                                 sizeof(uint32_t) * kWaveHistTiles;
+// The binning wavefront's lanes talk through LDS among themselves only: its "barrier" is the LDS
+// queue's own order (a wavefront's LDS operations complete in issue order) made explicit to the
+// compiler and to the wait counters — no s_barrier, so that the same code can run as one wavefront
+// of a wider workgroup (k_frame) whose other wavefronts have left.
+CR_DEV void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 template <int TS, bool PROJECT>
-__global__ __launch_bounds__(kWave) void k_setup_wave(const float *__restrict__ tri_in,
-                                                      const float *__restrict__ nrm,
-                                                      float *__restrict__ proj_out,
-                                                      uint32_t *__restrict__ count,
-                                                      float4 *__restrict__ bins, uint32_t dcap,
-                                                      uint32_t *__restrict__ hdr, HeavyReg hv, int64_t T,
-                                                      ProjConst P, Geom G)
+CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__restrict__ nrm,
+                            float *__restrict__ proj_out, uint32_t *__restrict__ count,
+                            float4 *__restrict__ bins, uint32_t dcap, uint32_t *__restrict__ hdr,
+                            const HeavyReg hv, int64_t T, const ProjConst &P, const Geom &G,
+                            int64_t group, unsigned char *lds)
 {
     constexpr int NP = kEntryPieces;                         // 16-byte pieces per entry
-    __shared__ __attribute__((aligned(16))) float sv[kWave * 9];
-    __shared__ __attribute__((aligned(16))) float4 img[kWave * NP];   // the wavefront's entries
-    __shared__ uint32_t hist[kWaveHistTiles];
+    float *sv = reinterpret_cast<float *>(lds);                                      // [kWave * 9]
+    float4 *img = reinterpret_cast<float4 *>(lds + sizeof(float) * kWave * 9);       // the wavefront's entries
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds + sizeof(float) * kWave * 9 + sizeof(float4) * kWave * NP);
     const int lane = threadIdx.x;
-    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    const int64_t b0 = group * kWave;
     const int n = (int)((T - b0) < kWave ? (T - b0) : kWave);
     CR_SETUP_STAMP(0);
     stage_in<kWave>(tri_in + b0 * 9, sv, n * 9);
@@ -551,7 +575,7 @@ __global__ __launch_bounds__(kWave) void k_setup_wave(const float *__restrict__ 
         const float *nn = nrm + (b0 + lane) * 9;
         nz0 = nn[2]; nz1 = nn[5]; nz2 = nn[8];
     }
-    __syncthreads();
+    wave_lds_sync();
     CR_SETUP_STAMP(1);      // inputs staged
     uint2 r = make_uint2(kNoTiles, 0);
     if (lane < n) {
@@ -591,7 +615,7 @@ __global__ __launch_bounds__(kWave) void k_setup_wave(const float *__restrict__ 
         X0 = min(X0, __shfl_xor(X0, d, 64)); X1 = max(X1, __shfl_xor(X1, d, 64));
         Y0 = min(Y0, __shfl_xor(Y0, d, 64)); Y1 = max(Y1, __shfl_xor(Y1, d, 64));
     }
-    __syncthreads();        // projected vertices and entries visible to every lane
+    wave_lds_sync();        // projected vertices and entries visible to every lane
     CR_SETUP_STAMP(2);      // projected, ranges known
     if (PROJECT) stage_out<kWave>(proj_out + b0 * 9, sv, n * 9);
     if (X1 < 0) return;     // nothing to bin (uniform)
@@ -601,9 +625,9 @@ __global__ __launch_bounds__(kWave) void k_setup_wave(const float *__restrict__ 
         return;
     }
     for (int i = lane; i < area; i += kWave) hist[i] = 0;
-    __syncthreads();
+    wave_lds_sync();
     for_each_tile_xy(r, [&](int tx, int ty, int) { atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u); });
-    __syncthreads();
+    wave_lds_sync();
     CR_SETUP_STAMP(3);      // pass A done
     {
         constexpr int kRounds = kWaveHistTiles / kWave;
@@ -629,7 +653,7 @@ __global__ __launch_bounds__(kWave) void k_setup_wave(const float *__restrict__ 
             }
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     CR_SETUP_STAMP(4);      // pass B done (global atomics returned)
     // a lane's own (narrow) range: every LDS cursor first, then the entries
     {
@@ -662,6 +686,20 @@ __global__ __launch_bounds__(kWave) void k_setup_wave(const float *__restrict__ 
         if (slot < dcap) put_entry<NP>(bins + ((size_t)(ty * G.ntx + tx) * dcap + slot) * NP, img, owner);
     });
     CR_SETUP_STAMP(5);      // entries issued
+}
+
+template <int TS, bool PROJECT>
+__global__ __launch_bounds__(kWave) void k_setup_wave(const float *__restrict__ tri_in,
+                                                      const float *__restrict__ nrm,
+                                                      float *__restrict__ proj_out,
+                                                      uint32_t *__restrict__ count,
+                                                      float4 *__restrict__ bins, uint32_t dcap,
+                                                      uint32_t *__restrict__ hdr, HeavyReg hv, int64_t T,
+                                                      ProjConst P, Geom G)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kSetupWaveLds];
+    setup_wave_body<TS, PROJECT>(tri_in, nrm, proj_out, count, bins, dcap, hdr, hv, T, P, G,
+                                 (int64_t)blockIdx.x, lds);
 }
 
 // ---- scan path, one wavefront per 64 triangles ------------------------------------------------
@@ -1350,18 +1388,22 @@ CR_DEV void build_order(const uint32_t *__restrict__ count, int ntx, int nty,
     }
 }
 
-template <int TS, bool CLEAR>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? CR_WPE16 : TS == 32 ? CR_WPE32 : 1)))
-void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
-              const float *__restrict__ nrm, TileLists L,
-              float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
-              int32_t *__restrict__ win, Geom G, int dbg_arg)
+// the batch: records array-of-structures on 16-pixel tiles (Rec16), else the WorkQueue
+template <int TS>
+constexpr size_t raster_queue_bytes()
 {
-    __shared__ unsigned long long key[TS * TS];
-    // the batch: records array-of-structures on 16-pixel tiles (Rec16), else the WorkQueue
-    constexpr size_t kQueueBytes = TS == 16 ? sizeof(Rec16) * kBatch16 + sizeof(uint32_t) * (kThreads + 8)
-                                            : sizeof(WorkQueue);
-    __shared__ __attribute__((aligned(16))) unsigned char qraw[kQueueBytes];
+    return TS == 16 ? sizeof(Rec16) * kBatch16 + sizeof(uint32_t) * (kThreads + 8) : sizeof(WorkQueue);
+}
+
+// Workgroup `b` of a raster launch (the kernels below hand in their LDS: k_frame runs binning
+// wavefronts of another frame in the same launch).
+template <int TS, bool CLEAR>
+CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict__ col,
+                        const float *__restrict__ nrm, const TileLists &L,
+                        float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
+                        int32_t *__restrict__ win, const Geom &G, int dbg_arg, int b,
+                        unsigned long long *key, unsigned char *qraw)
+{
     WorkQueue &q = *reinterpret_cast<WorkQueue *>(qraw);                 // (TS != 16 only)
     Rec16 *recs = reinterpret_cast<Rec16 *>(qraw);                       // (TS == 16 only)
     uint32_t *scan16 = reinterpret_cast<uint32_t *>(qraw + sizeof(Rec16) * kBatch16);
@@ -1378,7 +1420,6 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
 
     // ---- which tile, and which part of it --------------------------------------------------
     // grid = [order builder, if ordered][3 * hmax helpers][ntiles main workgroups, one tile each]
-    int b = (int)blockIdx.x;
     if (L.order_next) {
         if (b == 0) {
             build_order(L.count, G.ntx, G.nty, L.order_next, L.grouped_next, L.hint_next, reinterpret_cast<uint32_t *>(qraw));
@@ -1901,6 +1942,50 @@ void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
     }
 }
 
+template <int TS, bool CLEAR>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? CR_WPE16 : TS == 32 ? CR_WPE32 : 1)))
+void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
+              const float *__restrict__ nrm, TileLists L,
+              float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
+              int32_t *__restrict__ win, Geom G, int dbg_arg)
+{
+    __shared__ unsigned long long key[TS * TS];
+    __shared__ __attribute__((aligned(16))) unsigned char qraw[raster_queue_bytes<TS>()];
+    raster_body<TS, CLEAR>(proj, col, nrm, L, zb, cb, nb, win, G, dbg_arg, (int)blockIdx.x, key, qraw);
+}
+
+// One launch per frame for a stream of frames (crender_pipeline_*, direct bins): the raster pass of
+// frame i and, in its first `nsetup` workgroups, the binning pass of the NEXT frame on the same
+// stream — k_setup_wave's wavefronts, one per workgroup (threads 64..255 leave at once), working
+// into another plan.  Nothing in the launch depends on anything else in it.  The binning pass is a
+// latency chain of 216 wavefronts (T-Rex) that a launch of its own stretches to 8.6 us; here it
+// costs neither a launch nor the GPU's time between two launches of a stream.
+struct RasterArgs {
+    const float *proj, *col, *nrm;
+    TileLists L;
+    float *zb, *cb, *nb;
+    int32_t *win;
+    Geom G;
+    int dbg;
+};
+static_assert(kSetupWaveLds <= raster_queue_bytes<16>() && kSetupWaveLds <= raster_queue_bytes<32>(),
+              "a binning wavefront works in the raster workgroup's batch queue");
+template <int TS, bool CLEAR>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? CR_WPE16 : TS == 32 ? CR_WPE32 : 1)))
+void k_frame(RasterArgs R, SetupArgs S, int nsetup)
+{
+    __shared__ unsigned long long key[TS * TS];
+    __shared__ __attribute__((aligned(16))) unsigned char qraw[raster_queue_bytes<TS>()];
+    if ((int)blockIdx.x < nsetup) {
+        if (threadIdx.x < kWave)
+            setup_wave_body<TS, true>(S.tri_in, S.nrm, S.proj_out, S.count, S.bins, S.dcap, S.hdr, S.hv, S.T,
+                                      S.P, S.G, (int64_t)blockIdx.x, qraw);
+        return;
+    }
+    raster_body<TS, CLEAR>(R.proj, R.col, R.nrm, R.L, R.zb, R.cb, R.nb, R.win, R.G, R.dbg,
+                           (int)blockIdx.x - nsetup, key, qraw);
+}
+
 // ---- second implementation: global 64-bit atomics ---------------------------------
 __global__ __launch_bounds__(kThreads) void k_keys_init(unsigned long long *__restrict__ keys,
                                                         const float *__restrict__ zb,
@@ -2291,6 +2376,17 @@ struct crender_pipeline {
     hipStream_t s[kMaxPipelineDepth] = {};
     hipEvent_t done[kMaxPipelineDepth] = {};
     hipEvent_t mark = nullptr;
+    // look-ahead (crender_pipeline_set_lookahead): slot k alternates between plan[k] and ahead[k];
+    // the launch that rasterizes one of them bins the slot's NEXT frame into the other (k_frame)
+    crender_plan *ahead[kMaxPipelineDepth] = {};
+    int sel[kMaxPipelineDepth] = {};           // 0: plan[k] holds / takes the current frame, 1: ahead[k]
+    struct Primed {                            // what the slot's other plan has been binned for
+        bool ok = false;
+        const float *tri = nullptr, *nrm = nullptr;
+        int64_t T = 0;
+        float P[16] = {};
+        unsigned flags = 0;
+    } primed[kMaxPipelineDepth];
     uint64_t n = 0;           // frames submitted since the last join
     const void *last_tri = nullptr, *last_nrm = nullptr;
     int64_t last_T = -1;
@@ -2333,9 +2429,12 @@ int dev_knobs()
 #endif
 }
 
+// `defer` (crender_pipeline's look-ahead): when the pass is the one-launch direct-bin kernel its
+// arguments are handed back instead of launched, for k_frame to run it inside a raster launch.
 template <int TS>
 int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const float *d_nrm, int64_t T,
-                 const ProjConst &P, unsigned flags, hipStream_t s)
+                 const ProjConst &P, unsigned flags, hipStream_t s, SetupArgs *defer = nullptr,
+                 bool *deferred = nullptr)
 {
     const Layout &L = plan->L;
     const Geom G = L.g;
@@ -2384,6 +2483,12 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
             hv.hint_bad = plan->hdr() + 5 + par;
         }
         const unsigned nwg = (unsigned)((T + kWave - 1) / kWave);
+        if (defer && project && TS <= 32) {
+            *defer = SetupArgs{d_tri, d_nrm, plan->proj(), count, plan->direct(), (uint32_t)L.direct_cap,
+                               plan->hdr(), hv, T, P, G};
+            *deferred = true;
+            return CRENDER_OK;
+        }
         if (project)
             hipLaunchKernelGGL((k_setup_wave<TS, true>), dim3(nwg), dim3(kWave), 0, s, d_tri, d_nrm,
                                plan->proj(), count, plan->direct(), (uint32_t)L.direct_cap, plan->hdr(),
@@ -2460,7 +2565,7 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
 template <int TS>
 int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, const float *d_nrm,
                     float *d_z, float *d_color, float *d_normal, int32_t *d_winner, unsigned flags,
-                    hipStream_t s)
+                    hipStream_t s, const SetupArgs *with_setup = nullptr)
 {
     const Layout &L = plan->L;
     const Geom G = L.g;
@@ -2497,6 +2602,22 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     tl.vec_clear = (any & 15u) == 0 && (G.W & 3) == 0;
     tl.light = Light{plan->light[0], plan->light[1], plan->light[2], (flags & CRENDER_FUSED_GURO) ? 1 : 0};
     const unsigned grid = (unsigned)(G.ntiles + tl.nhelp + (ordered ? 1 : 0));
+    if constexpr (TS <= 32) {
+        if (with_setup) {
+            // this frame's raster pass and another plan's binning pass in one launch (k_frame)
+            const int nsetup = (int)((with_setup->T + kWave - 1) / kWave);
+            const RasterArgs ra{proj, d_col, d_nrm, tl, d_z, d_color, d_normal, d_winner, G, dbg};
+            if (flags & CRENDER_FUSED_CLEAR)
+                hipLaunchKernelGGL((k_frame<TS, true>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, ra,
+                                   *with_setup, nsetup);
+            else
+                hipLaunchKernelGGL((k_frame<TS, false>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, ra,
+                                   *with_setup, nsetup);
+            CR_LAUNCH_CHECK("k_frame");
+            plan->awaiting[par ^ 1] = false;
+            return CRENDER_OK;
+        }
+    }
     if (flags & CRENDER_FUSED_CLEAR)
         hipLaunchKernelGGL((k_raster<TS, true>), dim3(grid), dim3(kThreads), 0, s, proj, d_col, d_nrm, tl,
                            d_z, d_color, d_normal, d_winner, G, dbg);
@@ -2512,7 +2633,8 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     (plan->L.ts == 16 ? (call16) : plan->L.ts == 32 ? (call32) : (call64))
 
 int bin_pass(crender_plan *plan, bool project, const float *d_tri, const float *d_nrm, int64_t T,
-             const float *P16, unsigned flags, void *stream)
+             const float *P16, unsigned flags, void *stream, SetupArgs *defer = nullptr,
+             bool *deferred = nullptr)
 {
     if (!plan) return fail(CRENDER_EINVAL, "null plan");
     if (T < 0 || T > plan->L.max_T) return fail(CRENDER_EINVAL, "T exceeds the plan's max_T");
@@ -2522,14 +2644,14 @@ int bin_pass(crender_plan *plan, bool project, const float *d_tri, const float *
     std::memset(&P, 0, sizeof P);
     if (project) P = make_proj(P16, plan->L.g.W, plan->L.g.H);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return CR_BY_TILE(run_bin_pass<16>(plan, project, d_tri, d_nrm, T, P, flags, s),
-                      run_bin_pass<32>(plan, project, d_tri, d_nrm, T, P, flags, s),
-                      run_bin_pass<64>(plan, project, d_tri, d_nrm, T, P, flags, s));
+    return CR_BY_TILE(run_bin_pass<16>(plan, project, d_tri, d_nrm, T, P, flags, s, defer, deferred),
+                      run_bin_pass<32>(plan, project, d_tri, d_nrm, T, P, flags, s, defer, deferred),
+                      run_bin_pass<64>(plan, project, d_tri, d_nrm, T, P, flags, s, defer, deferred));
 }
 
 int raster_pass(crender_plan *plan, const float *proj, const float *d_col, const float *d_nrm, int64_t T,
                 float *d_z, float *d_color, float *d_normal, int32_t *d_winner, unsigned flags,
-                void *stream)
+                void *stream, const SetupArgs *with_setup = nullptr)
 {
     if (!plan) return fail(CRENDER_EINVAL, "null plan");
     if (T != plan->last_T) return fail(CRENDER_EINVAL, "T differs from the prepared frame's");
@@ -2540,8 +2662,8 @@ int raster_pass(crender_plan *plan, const float *proj, const float *d_col, const
     if (!d_z || !d_color || !d_normal) return fail(CRENDER_EINVAL, "null framebuffer pointer");
     if (T > 0 && (!proj || !d_col || !d_nrm)) return fail(CRENDER_EINVAL, "null triangle array");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return CR_BY_TILE(run_raster_pass<16>(plan, proj, d_col, d_nrm, d_z, d_color, d_normal, d_winner, flags, s),
-                      run_raster_pass<32>(plan, proj, d_col, d_nrm, d_z, d_color, d_normal, d_winner, flags, s),
+    return CR_BY_TILE(run_raster_pass<16>(plan, proj, d_col, d_nrm, d_z, d_color, d_normal, d_winner, flags, s, with_setup),
+                      run_raster_pass<32>(plan, proj, d_col, d_nrm, d_z, d_color, d_normal, d_winner, flags, s, with_setup),
                       run_raster_pass<64>(plan, proj, d_col, d_nrm, d_z, d_color, d_normal, d_winner, flags, s));
 }
 
@@ -2877,11 +2999,63 @@ int crender_pipeline_frame(crender_pipeline *p, const float *d_tri, const float 
         p->synced = true;
     }
     const int k = (int)(p->n % (uint64_t)p->depth);
+    if (p->ahead[k] && P16 && T > 0) {
+        // One launch per frame: this frame's raster pass together with the binning pass of the
+        // slot's NEXT frame — expected to come with the same inputs — into the slot's other plan.
+        // A frame whose plan was not binned for exactly these inputs (the first frames after a
+        // join, after new inputs) bins first, in a launch of its own.
+        if (!d_z || !d_color || !d_normal) return fail(CRENDER_EINVAL, "null framebuffer pointer");
+        if (!d_col) return fail(CRENDER_EINVAL, "null triangle array");
+        crender_plan *cur = p->sel[k] ? p->ahead[k] : p->plan[k];
+        crender_plan *nxt = p->sel[k] ? p->plan[k] : p->ahead[k];
+        crender_pipeline::Primed &pr = p->primed[k];
+        const bool have = pr.ok && pr.tri == d_tri && pr.nrm == d_nrm && pr.T == T && pr.flags == flags &&
+                          std::memcmp(pr.P, P16, sizeof pr.P) == 0;
+        pr.ok = false;
+        int rc = CRENDER_OK;
+        if (!have) rc = bin_pass(cur, true, d_tri, d_nrm, T, P16, flags, p->s[k]);
+        if (rc != CRENDER_OK) return rc;
+        SetupArgs sa;
+        bool deferred = false;
+        rc = bin_pass(nxt, true, d_tri, d_nrm, T, P16, flags, p->s[k], &sa, &deferred);
+        if (rc != CRENDER_OK) return rc;
+        rc = raster_pass(cur, cur->proj(), d_col, d_nrm, T, d_z, d_color, d_normal, d_winner, flags, p->s[k],
+                         deferred ? &sa : nullptr);
+        if (rc != CRENDER_OK) return rc;
+        pr.ok = true; pr.tri = d_tri; pr.nrm = d_nrm; pr.T = T; pr.flags = flags;
+        std::memcpy(pr.P, P16, sizeof pr.P);
+        p->sel[k] ^= 1;
+        p->n++;
+        return CRENDER_OK;
+    }
     // plan k and framebuffer set k were last used by frame n - depth, earlier on this same stream
     int rc = crender_render_model_on(p->plan[k], d_tri, d_col, d_nrm, T, P16, d_z, d_color, d_normal,
                                      d_winner, flags, p->s[k]);
     if (rc != CRENDER_OK) return rc;
     p->n++;
+    return CRENDER_OK;
+}
+
+int crender_pipeline_set_lookahead(crender_pipeline *p, crender_plan *const *plans, int n)
+{
+    if (!p) return fail(CRENDER_EINVAL, "null pipeline");
+    if (p->n != 0) return fail(CRENDER_EINVAL, "crender_pipeline_set_lookahead: frames in flight (join first)");
+    if (!plans || n == 0) {
+        for (int k = 0; k < p->depth; ++k) { p->ahead[k] = nullptr; p->sel[k] = 0; p->primed[k].ok = false; }
+        return CRENDER_OK;
+    }
+    if (n != p->depth) return fail(CRENDER_EINVAL, "crender_pipeline_set_lookahead: one plan per slot");
+    for (int i = 0; i < n; ++i) {
+        if (!plans[i]) return fail(CRENDER_EINVAL, "crender_pipeline_set_lookahead: null plan");
+        for (int j = 0; j < p->depth; ++j)
+            if (plans[i] == p->plan[j] || (j < i && plans[i] == plans[j]))
+                return fail(CRENDER_EINVAL, "crender_pipeline_set_lookahead: plans must be distinct");
+        const Layout &a = plans[i]->L, &b = p->plan[i]->L;
+        if (a.ts != b.ts || a.g.W != b.g.W || a.g.H != b.g.H || a.g.y0 != b.g.y0 || a.g.y1 != b.g.y1 ||
+            a.max_T != b.max_T)
+            return fail(CRENDER_EINVAL, "crender_pipeline_set_lookahead: a slot's two plans must be alike");
+    }
+    for (int k = 0; k < p->depth; ++k) { p->ahead[k] = plans[k]; p->sel[k] = 0; p->primed[k].ok = false; }
     return CRENDER_OK;
 }
 
@@ -2919,6 +3093,9 @@ int crender_pipeline_join(crender_pipeline *p, void *stream)
     }
     p->n = 0;
     p->synced = false;   // the next frame re-synchronises with the caller's stream
+    // the caller may write new inputs behind a join: what was binned ahead from the old ones is void
+    // (the abandoned plan starts over like after two crender_prepare calls in a row)
+    for (int k = 0; k < p->depth; ++k) p->primed[k].ok = false;
     return CRENDER_OK;
 }
 

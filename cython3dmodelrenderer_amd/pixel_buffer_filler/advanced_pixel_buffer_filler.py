@@ -71,6 +71,9 @@ _current_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream",
 _current_device = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)
 
 
+_DIRECT_MAX_TRIANGLES = 1 << 16      # kDirectMaxTriangles of crender_hip.hip: beyond, count / scan / fill
+
+
 class _FramePipeline:
     """Swap chain for ``render_frame`` (``crender_pipeline_*``): frame i renders on the library's
     stream i % depth with plan i % depth into framebuffer set i % depth, so up to `depth` frames
@@ -85,7 +88,11 @@ class _FramePipeline:
         self.device = filler.device
         self.depth = int(depth)
         self.plans, self.workspaces = [], []
-        for _ in range(self.depth):
+        # look-ahead (crender_pipeline_set_lookahead): a second plan per slot, so that the launch that
+        # rasterizes a frame also bins the slot's next one — scenes that fit the direct bins
+        self.lookahead = 0 < int(T) <= _DIRECT_MAX_TRIANGLES and filler._extra_flags == 0 \
+            if filler._lookahead is None else bool(filler._lookahead)
+        for _ in range(self.depth * (2 if self.lookahead else 1)):
             cap = max(filler._bin_request, filler._bin_floor)
             nbytes = self.lib.crender_plan_workspace_bytes(filler.h, filler.w, filler.y0, filler.y1,
                                                            max(int(T), 1), cap, filler.tile)
@@ -99,10 +106,14 @@ class _FramePipeline:
             self.workspaces.append(ws)
         self.max_T = max(int(T), 1)
         self.handle = C.c_void_p()
-        arr = (C.c_void_p * self.depth)(*[p.value for p in self.plans])
+        arr = (C.c_void_p * self.depth)(*[p.value for p in self.plans[:self.depth]])
         with torch.cuda.device(self.device):       # the pipeline's streams live on this device
             _capi.check(self.lib.crender_pipeline_create(C.byref(self.handle), arr, self.depth),
                         "crender_pipeline_create")
+            if self.lookahead:
+                more = (C.c_void_p * self.depth)(*[p.value for p in self.plans[self.depth:]])
+                _capi.check(self.lib.crender_pipeline_set_lookahead(self.handle, more, self.depth),
+                            "crender_pipeline_set_lookahead")
         # framebuffer sets of the swap chain: the filler's own buffers and copies of them
         front = (filler.z_buffer, filler.color_buffer, filler.normals_buffer, filler.winner_buffer)
         self.sets = [front] + [tuple(None if t is None else t.clone() for t in front)
@@ -182,7 +193,7 @@ class AdvancedPixelBufferFiller:
     def __init__(self, h, w, fov=90.0, z_near=0.1, z_far=1000.0, n_threads=1, *,
                  device=None, tile=0, row_strip=None, track_winner=False, cache_inputs=False,
                  bin_capacity=0, direct_bins=True, pipeline=False, pipeline_depth=None,
-                 presort=None):
+                 presort=None, lookahead=None):
         self._lib = _capi.load()                      # raises if the HIP library is missing
         self._ext = _torch_ext.load()                 # raises if the torch extension is not built
         if not torch.cuda.is_available():
@@ -226,6 +237,9 @@ class AdvancedPixelBufferFiller:
         # Tile-coherent copy of large models (crender_plan_set_triangle_order): None = from 2^18
         # triangles on, True / False = always / never.  Made once per upload; results do not change.
         self._presort = presort
+        # swap chain: the launch that rasterizes a frame also bins the slot's next frame into a second
+        # plan (crender_pipeline_set_lookahead).  None = for scenes that fit the direct bins.
+        self._lookahead = lookahead
         self._order = None             # (orig_of, pos_of) int32 device tensors of the resident inputs
         self._plan_order = None        # what the single-stream plan currently holds
         self._fused_light = None       # (l0, l1, l2): illumination fused into cleared frames

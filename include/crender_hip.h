@@ -206,6 +206,16 @@ CRENDER_API int crender_pipeline_frame(crender_pipeline *pipeline, const float *
                            float *d_z, float *d_color, float *d_normal, int32_t *d_winner,
                            unsigned flags, void *stream);
 CRENDER_API int crender_pipeline_join(crender_pipeline *pipeline, void *stream);
+/* Look-ahead: give every slot a second plan (`plans`: `depth` plans, each like the slot's first,
+ * distinct from all others; n = 0 or plans = NULL switches it off; only between joins).  Slot k then
+ * alternates between its two plans, and the launch that rasterizes frame i also bins the slot's next
+ * frame (i + depth) — expected to arrive with the same inputs, projection matrix and flags — into the
+ * other plan: one launch per frame instead of two, and the binning pass (a latency chain of a few
+ * hundred wavefronts) costs no launch of its own.  A frame that arrives with other arguments, and
+ * every slot's first frame after a join (the caller may have written new inputs), bins in a launch
+ * of its own first, exactly as without look-ahead.  Scenes on the count / scan / fill path gain
+ * nothing (their passes are launched as before).  Bin-list usage is queried per plan, all 2 x depth. */
+CRENDER_API int crender_pipeline_set_lookahead(crender_pipeline *pipeline, crender_plan *const *plans, int n);
 /* The same with the per-frame arguments bound up front, for callers whose call overhead grows with
  * the argument count (ctypes: ~4 us for crender_pipeline_frame's twelve): bind slot k = 0..depth-1
  * (the arguments frame i with i % depth == k is to use; P16 is copied), then every

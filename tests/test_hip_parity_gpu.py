@@ -889,6 +889,50 @@ def test_synthetic_10m_matches_golden(hip, golden):
         assert_bit_equal(a, b, f"synth10m: tile path vs atomic path, {what}")
 
 
+@pytest.mark.parametrize("res,tile", [(512, 0), (1024, 0), (1536, 0)])
+def test_pipeline_lookahead_bins_the_next_frame_in_the_raster_launch(oracle, res, tile):
+    """Swap chain with look-ahead (crender_pipeline_set_lookahead): every launch rasterizes one frame
+    and bins the slot's next one into a second plan.  Frames must be the oracle's whatever the
+    history: bursts of any length, a join in between, another model (the plans were binned ahead for
+    the old one), back again, and look-ahead off for comparison — 16- and 32-pixel tiles."""
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    tri, col, nrm = scene("trex_inputs.npz")
+    ctri, ccol, cnrm = scene("cube_inputs.npz")
+    ft, fc = oracle.OracleFiller(res, res, fov=45), oracle.OracleFiller(res, res, fov=45)
+    ft.render_arrays(tri, col, nrm)
+    fc.render_arrays(ctri, ccol, cnrm)
+
+    def check(filler, f, what):
+        assert_bit_equal(filler.get_z_buffer(), f.z_buffer, f"{what}: z")
+        assert_bit_equal(filler.get_color_buffer(), f.color_buffer, f"{what}: colour")
+        assert_bit_equal(filler.get_normals_buffer(), f.normals_buffer, f"{what}: normal")
+        assert_bit_equal(filler.get_winner_tensor().cpu().numpy(), f.winner, f"{what}: winner")
+
+    for look in (True, False):
+        filler = AdvancedPixelBufferFiller(res, res, fov=45, tile=tile, pipeline=True, track_winner=True,
+                                           lookahead=look)
+        filler.render_arrays(tri, col, nrm, clear=True)
+        assert filler._pipe is None or filler._pipe.lookahead == look
+        for burst in (1, 2, 3, 4, 5, 9):
+            for _ in range(burst):
+                filler.render_frame()
+            assert filler._pipe.lookahead == look
+            check(filler, ft, f"look-ahead {look}, T-Rex after a burst of {burst}")
+        filler.render_arrays(ctri, ccol, cnrm, clear=True)          # other inputs: nothing binned ahead fits
+        for burst in (1, 6):
+            for _ in range(burst):
+                filler.render_frame()
+            check(filler, fc, f"look-ahead {look}, cube after a burst of {burst}")
+        filler.render_arrays(tri, col, nrm, clear=True)
+        for _ in range(7):
+            filler.render_frame()
+        check(filler, ft, f"look-ahead {look}, T-Rex again")
+        # every framebuffer set of the chain holds the frame
+        for k, (z, c, n, w) in enumerate(filler._pipe.sets):
+            assert_bit_equal(z.cpu().numpy(), ft.z_buffer, f"set {k}: z")
+            assert_bit_equal(c.cpu().numpy(), ft.color_buffer, f"set {k}: colour")
+
+
 @pytest.mark.parametrize("name,fixture,res,depth", [("bunny4096", "bunny_inputs.npz", 4096, 3),
                                                     ("trex8192", "trex_inputs.npz", 8192, 3)])
 def test_pipelined_frames_at_bench_sizes(golden, name, fixture, res, depth):
