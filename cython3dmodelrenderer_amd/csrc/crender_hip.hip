@@ -28,7 +28,8 @@
 //   scatter-dispatch rule, 512 no row rotation of the tile map, 4096 coarse pass keeps every
 //   block, 8192 large-record sweep for every batch (32/64-pixel tiles), bits 16..23 = n + 1:
 //   pixel-parallel path of 16-pixel tiles for batches <= n records (n = 0 disables it; default
-//   kPixelPathRecords).
+//   kPixelPathRecords), 16384 frames of a swap chain are treated as lone frames (ordered dispatch
+//   and split tiles although they overlap).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -1181,7 +1182,7 @@ CR_DEV void coarse_cull(WorkQueue &q, const uint32_t *wo, int total, int tid,
 __device__ unsigned long long *g_stamps = nullptr;
 #define CR_STAMP(slot)                                                             \
     do {                                                                           \
-        if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64(); \
+        if (g_stamps && threadIdx.x == 0) g_stamps[stamp_base + (slot)] = wall_clock64(); \
     } while (0)
 #else
 #define CR_STAMP(slot) do { } while (0)
@@ -1193,6 +1194,27 @@ __device__ unsigned long long *g_stamps = nullptr;
 // Every address is a uniform base (the rectangle's first pixel) plus a 32-bit per-thread offset:
 // the empty tiles are three quarters of a 1024^2 frame's workgroups and their instruction count
 // is part of the launch's (64-bit per-thread address arithmetic tripled it).
+// The background goes out write-through (sc1): a plain store allocates its line in the XCD's L2 and
+// 28 MB of them per 1024^2 frame push the lists and records the covered tiles are about to read out
+// of it; write-through stores cost the same and leave the L2 alone (T-Rex 1024^2: one frame alone
+// 22.8 -> 21.7 us, a launch that only clears 6.8 -> 6.2 us per frame in flight).
+#ifndef CR_CLEAR_POLICY
+#define CR_CLEAR_POLICY 1      // 0 plain, 1 sc1 (write-through), 2 nt
+#endif
+typedef float cr_v4f __attribute__((ext_vector_type(4)));
+CR_DEV void st4(float *p, const float4 &v)
+{
+#if CR_CLEAR_POLICY == 0
+    *reinterpret_cast<float4 *>(p) = v;
+#else
+    const cr_v4f x = {v.x, v.y, v.z, v.w};
+#if CR_CLEAR_POLICY == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(x) : "memory");
+#endif
+#endif
+}
 template <int TS>
 CR_DEV void clear_rect(float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
                        int32_t *__restrict__ win, int W, int X0, int Y0, int X1, int Y1, bool vec, int tid)
@@ -1216,24 +1238,24 @@ CR_DEV void clear_rect(float *__restrict__ zb, float *__restrict__ cb, float *__
             const uint32_t r1 = t / CQ, off1 = r1 * uW * 3 + (t - r1 * CQ) * 4;
             if (t < 64) {
                 const uint32_t off0 = (t >> 2) * uW + (t & 3) * 4;
-                *reinterpret_cast<float4 *>(z0 + off0) = zv;
+                st4(z0 + off0, zv);
                 if (w0) *reinterpret_cast<int4 *>(w0 + off0) = wv;
             } else {
                 const uint32_t k = t - 64, r0 = k / CQ;
-                *reinterpret_cast<float4 *>(c0 + r0 * uW * 3 + (k - r0 * CQ) * 4) = ov;
+                st4(c0 + r0 * uW * 3 + (k - r0 * CQ) * 4, ov);
             }
-            if (t < 192) *reinterpret_cast<float4 *>(n0 + off1) = ov;
+            if (t < 192) st4(n0 + off1, ov);
             return;
         }
         for (uint32_t i = t; i < rows * ZQ; i += kThreads) {
             const uint32_t r = i / ZQ, off = r * uW + (i - r * ZQ) * 4;
-            *reinterpret_cast<float4 *>(z0 + off) = zv;
+            st4(z0 + off, zv);
             if (w0) *reinterpret_cast<int4 *>(w0 + off) = wv;
         }
         for (uint32_t i = t; i < rows * CQ; i += kThreads) {
             const uint32_t r = i / CQ, off = r * uW * 3 + (i - r * CQ) * 4;
-            *reinterpret_cast<float4 *>(c0 + off) = ov;
-            *reinterpret_cast<float4 *>(n0 + off) = ov;
+            st4(c0 + off, ov);
+            st4(n0 + off, ov);
         }
         return;
     }
@@ -1404,6 +1426,10 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                         int32_t *__restrict__ win, const Geom &G, int dbg_arg, int b,
                         unsigned long long *key, unsigned char *qraw)
 {
+#ifdef CRENDER_STAMPS
+    // frames of a swap chain stamp into a region of their slot (bits 24..26 of dbg_arg), 8192 workgroups each
+    const size_t stamp_base = ((size_t)((dbg_arg >> 24) & 7) * 8192 + blockIdx.x) * 16;
+#endif
     WorkQueue &q = *reinterpret_cast<WorkQueue *>(qraw);                 // (TS != 16 only)
     Rec16 *recs = reinterpret_cast<Rec16 *>(qraw);                       // (TS == 16 only)
     uint32_t *scan16 = reinterpret_cast<uint32_t *>(qraw + sizeof(Rec16) * kBatch16);
@@ -1510,9 +1536,9 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     CR_STAMP(0);
 #ifdef CRENDER_STAMPS
     if (g_stamps && threadIdx.x == 0) {
-        g_stamps[(size_t)blockIdx.x * 16 + 7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID
-        g_stamps[(size_t)blockIdx.x * 16 + 8] = (unsigned long long)tile;
-        g_stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memtime();
+        g_stamps[stamp_base + 7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID
+        g_stamps[stamp_base + 8] = (unsigned long long)tile;
+        g_stamps[stamp_base + 10] = __builtin_amdgcn_s_memtime();
     }
 #endif
     // the tile's triangle list: a run of the scanned index array, or (direct bins, offs == null)
@@ -1584,8 +1610,8 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     CR_STAMP(1);
 #ifdef CRENDER_STAMPS
     if (g_stamps && tid == 0) {
-        g_stamps[(size_t)blockIdx.x * 16 + 4] = end - beg;
-        g_stamps[(size_t)blockIdx.x * 16 + 9] = (unsigned long long)(quad + 1);
+        g_stamps[stamp_base + 4] = end - beg;
+        g_stamps[stamp_base + 9] = (unsigned long long)(quad + 1);
     }
 #endif
 
@@ -1929,7 +1955,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     }
     CR_STAMP(3);
 #ifdef CRENDER_STAMPS
-    if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memtime();
+    if (g_stamps && threadIdx.x == 0) g_stamps[stamp_base + 11] = __builtin_amdgcn_s_memtime();
 #endif
     }   // work
     // hand-off words of a heavy tile go back to zero once every wavefront has read them
@@ -2329,6 +2355,7 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
 struct crender_plan {
     Layout L;
     unsigned char *ws;
+    int stamp_slot = 0;        // (diagnostic build: which region of the stamp buffer its raster launches use)
     // optional per-frame HIP events (crender_plan_timing_begin): 3 per frame —
     // before the binning passes, before k_raster, after k_raster
     std::vector<hipEvent_t> events;
@@ -2445,7 +2472,7 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
     plan->last_T = T;
     const int par = (int)(plan->frame_no++ & 1u);
     plan->parity = par;
-    plan->frame_lone = !(flags & CRENDER_OVERLAPPED_FRAMES);
+    plan->frame_lone = !(flags & CRENDER_OVERLAPPED_FRAMES) || (dbg & 16384);
     if (plan->awaiting[par]) {
         // this parity was binned into and no raster pass has run since (two crender_prepare calls
         // in a row): start over from the state crender_plan_create leaves
@@ -2569,7 +2596,11 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
 {
     const Layout &L = plan->L;
     const Geom G = L.g;
+#ifdef CRENDER_STAMPS
+    const int dbg = dev_knobs() | (plan->stamp_slot << 24);
+#else
     const int dbg = dev_knobs();
+#endif
     const bool direct = plan->last_frame_direct;
     const int par = plan->parity;
     TileLists tl;
@@ -2955,6 +2986,7 @@ int crender_pipeline_create(crender_pipeline **out, crender_plan *const *plans, 
     hipError_t e = hipSuccess;
     for (int k = 0; k < depth && e == hipSuccess; ++k) {
         p->plan[k] = plans[k];
+        plans[k]->stamp_slot = k;
         e = hipStreamCreateWithFlags(&p->s[k], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done[k], hipEventDisableTiming);
     }
@@ -3055,7 +3087,7 @@ int crender_pipeline_set_lookahead(crender_pipeline *p, crender_plan *const *pla
             a.max_T != b.max_T)
             return fail(CRENDER_EINVAL, "crender_pipeline_set_lookahead: a slot's two plans must be alike");
     }
-    for (int k = 0; k < p->depth; ++k) { p->ahead[k] = plans[k]; p->sel[k] = 0; p->primed[k].ok = false; }
+    for (int k = 0; k < p->depth; ++k) { p->ahead[k] = plans[k]; plans[k]->stamp_slot = k; p->sel[k] = 0; p->primed[k].ok = false; }
     return CRENDER_OK;
 }
 
