@@ -13,6 +13,8 @@ python bench.py --workload synth10m --steps 10 --warmup 2 > $OUT/bench_synth10m.
 python bench.py --workload cube256 --steps 200 > $OUT/bench_cube256.json 2>/dev/null
 WL="trex1024 cube256" scripts/ab_lookahead.sh > $OUT/lookahead.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w scripts/ubench/clear_shapes.hip -o /tmp/clear_shapes && /tmp/clear_shapes > $OUT/clear_shapes.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w scripts/ubench/frame_shape.hip -o /tmp/frame_shape && /tmp/frame_shape > $OUT/frame_shape.txt 2>&1
+python scripts/stamps_overlap.py trex1024 > $OUT/stamps_overlap_trex1024.txt 2>&1
 python scripts/hostcost.py > $OUT/hostcost.txt 2>/dev/null
 python scripts/k20_host.py > $OUT/k20_host.txt 2>/dev/null
 for w in trex1024 bunny4096 trex8192 synth10m; do
