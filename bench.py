@@ -330,7 +330,9 @@ def main():
                          "avg_launch_ms": launch_ms,
                          "avg_launch_ms_how": "max(HIP events around the launch, single-stream frame "
                                               "time minus event-measured bin passes)",
-                         "traffic": load_traffic(args.workload)},
+                         # PMC bytes of the committed profile are per WHOLE-frame launch: a strip's
+                         # launch was not profiled
+                         "traffic": load_traffic(args.workload) if rows == H else None},
             "bin_entries": {"needed": need, "capacity": cap},
         }
         if not args.no_cpu_baseline and world == 1:
