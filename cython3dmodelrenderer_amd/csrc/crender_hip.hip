@@ -3061,6 +3061,10 @@ int crender_pipeline_frame(crender_pipeline *p, const float *d_tri, const float 
         return CRENDER_OK;
     }
     // plan k and framebuffer set k were last used by frame n - depth, earlier on this same stream
+    // (a frame that cannot look ahead — no triangles, projected input — takes the slot's first plan
+    // whatever was binned ahead: that is void then)
+    p->primed[k].ok = false;
+    p->sel[k] = 0;
     int rc = crender_render_model_on(p->plan[k], d_tri, d_col, d_nrm, T, P16, d_z, d_color, d_normal,
                                      d_winner, flags, p->s[k]);
     if (rc != CRENDER_OK) return rc;

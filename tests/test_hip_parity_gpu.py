@@ -704,6 +704,87 @@ def test_pipeline_c_abi_frame_bind_submit(oracle, hip):
         lib.crender_pipeline_destroy(pipe)
 
 
+@pytest.mark.parametrize("H,W,flags_extra", [(1024, 1024, 0), (1024, 1024, 4), (700, 900, 0)])
+def test_pipeline_c_abi_lookahead(oracle, hip, H, W, flags_extra):
+    """crender_pipeline_set_lookahead called directly: argument errors; frames whose raster launch
+    also bins the slot's next frame, as LONE frames (ordered dispatch, split heavy tiles: flags
+    without CRENDER_OVERLAPPED_FRAMES) and as overlapped ones; another model in between, a frame
+    of projected input (cannot look ahead) in between, a join in between; every framebuffer set
+    ends up the oracle's frame of what it was last asked to render."""
+    import ctypes as C
+    import torch
+    from cython3dmodelrenderer_amd import _capi
+    L = hip
+    lib = _capi.load()
+    tri, col, nrm = scene("trex_inputs.npz")
+    ctri, ccol, cnrm = scene("cube_inputs.npz")
+    depth = 3
+    ft, fc = oracle.OracleFiller(H, W, fov=45), oracle.OracleFiller(H, W, fov=45)
+    ft.render_arrays(tri, col, nrm)
+    fc.render_arrays(ctri, ccol, cnrm)
+    P = L.projection_matrix(45, 0.1, 1000.0, H, W)
+    d = [torch.from_numpy(a).cuda() for a in (tri, col, nrm)]
+    dc = [torch.from_numpy(a).cuda() for a in (ctri, ccol, cnrm)]
+    T, Tc = d[0].shape[0], dc[0].shape[0]
+    plans = [L.Plan(H, W, T) for _ in range(2 * depth)]
+    other = L.Plan(H, W, T + 5)
+    fbs = [L.FrameBuffers(H, W, winner=True) for _ in range(depth)]
+    arr = (C.c_void_p * depth)(*[p.handle.value for p in plans[:depth]])
+    more = (C.c_void_p * depth)(*[p.handle.value for p in plans[depth:]])
+    pipe = C.c_void_p()
+    _capi.check(lib.crender_pipeline_create(C.byref(pipe), arr, depth), "create")
+    stream = torch.cuda.current_stream().cuda_stream
+    flags = _capi.FUSED_CLEAR | flags_extra
+
+    def frame(inputs, n, k):
+        fb = fbs[k]
+        _capi.check(lib.crender_pipeline_frame(
+            pipe, inputs[0].data_ptr(), inputs[1].data_ptr(), inputs[2].data_ptr(), n, _capi.f32_16(P),
+            fb.z.data_ptr(), fb.color.data_ptr(), fb.normals.data_ptr(), fb.winner.data_ptr(), flags, stream), "frame")
+
+    def check(expect, what):
+        _capi.check(lib.crender_pipeline_join(pipe, stream), "join")
+        for k, fb in enumerate(fbs):
+            z, c, n, w = fb.numpy()
+            f = expect[k]
+            assert_bit_equal(z, f.z_buffer, f"{what}: set {k} z")
+            assert_bit_equal(c, f.color_buffer, f"{what}: set {k} colour")
+            assert_bit_equal(n, f.normals_buffer, f"{what}: set {k} normal")
+            assert_bit_equal(w, f.winner, f"{what}: set {k} winner")
+
+    try:
+        assert lib.crender_pipeline_set_lookahead(pipe, more, depth - 1) == _capi.EINVAL          # one per slot
+        assert lib.crender_pipeline_set_lookahead(pipe, arr, depth) == _capi.EINVAL               # not distinct
+        bad = (C.c_void_p * depth)(*([p.handle.value for p in plans[depth:2 * depth - 1]] + [other.handle.value]))
+        assert lib.crender_pipeline_set_lookahead(pipe, bad, depth) == _capi.EINVAL               # unlike plans
+        _capi.check(lib.crender_pipeline_set_lookahead(pipe, more, depth), "set_lookahead")
+        n = 0
+        for burst in (1, 2, 3, 7):                         # T-Rex, bursts with joins in between
+            for _ in range(burst):
+                frame(d, T, n % depth); n += 1
+            if n >= depth:
+                check([ft] * depth, f"T-Rex after a burst of {burst}")
+                n = 0
+        for _ in range(depth):                             # every slot binned ahead for T-Rex: now the cube
+            frame(d, T, n % depth); n += 1
+        for _ in range(depth + 1):
+            frame(dc, Tc, n % depth); n += 1
+        check([fc] * depth, "cube after T-Rex without a join"); n = 0
+        for i in range(2 * depth):                         # alternating models: nothing binned ahead ever fits
+            frame(d if i % 2 == 0 else dc, T if i % 2 == 0 else Tc, n % depth); n += 1
+        last = {}
+        for i in range(2 * depth):
+            last[i % depth] = ft if i % 2 == 0 else fc
+        check([last[k] for k in range(depth)], "alternating models"); n = 0
+        assert lib.crender_pipeline_set_lookahead(pipe, None, 0) == _capi.OK                      # off again
+        for _ in range(depth + 2):
+            frame(d, T, n % depth); n += 1
+        check([ft] * depth, "look-ahead switched off")
+    finally:
+        torch.cuda.synchronize()
+        lib.crender_pipeline_destroy(pipe)
+
+
 def test_renderer_with_illumination(oracle):
     from cython3dmodelrenderer_amd import Renderer
     from cython3dmodelrenderer_amd.illumination import GuroIllumination
@@ -923,6 +1004,11 @@ def test_pipeline_lookahead_bins_the_next_frame_in_the_raster_launch(oracle, res
             for _ in range(burst):
                 filler.render_frame()
             check(filler, fc, f"look-ahead {look}, cube after a burst of {burst}")
+        none = np.zeros((0, 3, 3), np.float32)                      # frames of no triangles in between
+        filler.render_arrays(none, none, none, clear=True)
+        for _ in range(5):
+            filler.render_frame()
+        assert int((filler.get_z_buffer() != np.float32(1e6)).sum()) == 0, f"look-ahead {look}: empty frame"
         filler.render_arrays(tri, col, nrm, clear=True)
         for _ in range(7):
             filler.render_frame()
