@@ -16,6 +16,7 @@ FUSED_CLEAR = 1
 NO_DIRECT_BINS = 2
 OVERLAPPED_FRAMES = 4
 FUSED_GURO = 8
+STATIC_INPUTS = 16
 
 _vp, _i32, _i64, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint, C.c_size_t
 _f32p = C.POINTER(C.c_float)

@@ -3101,6 +3101,7 @@ int crender_pipeline_bind(crender_pipeline *p, int slot, const float *d_tri, con
 {
     if (!p || slot < 0 || slot >= p->depth) return fail(CRENDER_EINVAL, "crender_pipeline_bind: bad slot");
     crender_pipeline::Bound &b = p->bound[slot];
+    p->primed[slot].ok = false;          // a new binding may bring new contents at old addresses
     b.tri = d_tri; b.col = d_col; b.nrm = d_nrm; b.T = T;
     b.has_P = P16 != nullptr;
     if (P16) std::memcpy(b.P, P16, sizeof b.P);
@@ -3130,8 +3131,10 @@ int crender_pipeline_join(crender_pipeline *p, void *stream)
     p->n = 0;
     p->synced = false;   // the next frame re-synchronises with the caller's stream
     // the caller may write new inputs behind a join: what was binned ahead from the old ones is void
-    // (the abandoned plan starts over like after two crender_prepare calls in a row)
-    for (int k = 0; k < p->depth; ++k) p->primed[k].ok = false;
+    // (the abandoned plan starts over like after two crender_prepare calls in a row) — unless the
+    // frames came with the promise that the arrays' contents stay (CRENDER_STATIC_INPUTS)
+    for (int k = 0; k < p->depth; ++k)
+        if (!(p->primed[k].flags & CRENDER_STATIC_INPUTS)) p->primed[k].ok = false;
     return CRENDER_OK;
 }
 

@@ -135,7 +135,8 @@ class _FramePipeline:
         self.plans = []
 
     def frame(self, filler):
-        want = (filler._inputs, filler._extra_flags, filler._fused_light, filler._order)
+        want = (filler._inputs, filler._extra_flags | (_capi.STATIC_INPUTS if filler._inputs_private else 0),
+                filler._fused_light, filler._order)
         if self._args is None or self._args[0] is not want[0] or self._args[1:3] != want[1:3] or self._args[3] is not want[3]:
             # everything but the stream is fixed while the resident model is: bind the arguments
             # of every slot once, the per-frame call then passes two (ctypes spends ~0.3 us per
@@ -154,7 +155,7 @@ class _FramePipeline:
                                 "crender_plan_set_light")
             for k, (z, c, n, w) in enumerate(self.sets):
                 filler._ext.pipeline_bind(self.handle.value, k, tri, col, nrm, filler._P_t, z, c, n, w,
-                                          _capi.FUSED_CLEAR | _capi.OVERLAPPED_FRAMES | guro | filler._extra_flags)
+                                          _capi.FUSED_CLEAR | _capi.OVERLAPPED_FRAMES | guro | want[1])
             self._args = want
         if _current_device() == self._index:
             self._submit(self._handle_int, self._index)
@@ -227,6 +228,8 @@ class AdvancedPixelBufferFiller:
         self._plan_capacity = 0
         self._workspace = None
         self._inputs = None            # (tri, col, nrm) device tensors of the last frame
+        self._inputs_private = False   # they are this filler's own copies (uploaded numpy arrays, or
+                                       # the tile-coherent copy): nobody else can change their contents
         self._input_key = None
         self._last_flags = 0
         self._extra_flags = 0 if direct_bins else _capi.NO_DIRECT_BINS
@@ -324,7 +327,7 @@ class AdvancedPixelBufferFiller:
     def _win_ptr(self):
         return self.winner_buffer.data_ptr() if self.winner_buffer is not None else None
 
-    def _launch(self, flags, inputs=None):
+    def _launch(self, flags, inputs=None, private=False):
         self._join_pipe()
         if self._unverified and not self._checking and not (flags & _capi.FUSED_CLEAR):
             # This frame composites on top of the previous one.  If that one overflowed its bin
@@ -334,6 +337,7 @@ class AdvancedPixelBufferFiller:
             self._check_bins()
         if inputs is not None:
             self._inputs, self._order = self._tile_coherent(inputs)
+            self._inputs_private = bool(private) or self._order is not None
         tri, col, nrm = self._inputs
         T = tri.shape[0]
         self._ensure_plan(T)
@@ -450,7 +454,8 @@ class AdvancedPixelBufferFiller:
             self._host_exposed = False
         else:
             self._push_host_edits()
-        self._launch(_capi.FUSED_CLEAR if clear else 0, inputs)   # (a pending overflow check needs the OLD inputs first)
+        self._launch(_capi.FUSED_CLEAR if clear else 0, inputs,    # (a pending overflow check needs the OLD inputs first)
+                     private=not any(isinstance(a, torch.Tensor) for a in src))
         if self._host:
             # arrays handed out earlier are views of the reference's own buffers there: they show
             # this render too
@@ -479,7 +484,8 @@ class AdvancedPixelBufferFiller:
             self._host_exposed = False
         else:
             self._push_host_edits()
-        self._launch(_capi.FUSED_CLEAR if clear else 0, inputs)
+        self._launch(_capi.FUSED_CLEAR if clear else 0, inputs,
+                     private=not any(isinstance(a, torch.Tensor) for a in (tri, col, nrm)))
 
     def set_fused_illumination(self, light_direction=None):
         """Fuse ``GuroIllumination(light_direction).draw_illumination`` into every frame that starts

@@ -75,7 +75,13 @@ enum {
      * with CRENDER_FUSED_CLEAR: the reference shades the WHOLE buffer after every render, which a
      * frame can only reproduce pixel by pixel when it starts from cleared buffers (background
      * colour 0 stays 0).  Same result as the render followed by crender_guro_illumination. */
-    CRENDER_FUSED_GURO = 8u
+    CRENDER_FUSED_GURO = 8u,
+    /* crender_pipeline_* with look-ahead only: the CONTENTS of the triangle arrays do not change
+     * for as long as the same arguments keep coming (e.g. a private device copy of a model), so
+     * what was binned ahead for a slot stays valid across crender_pipeline_join.  Without it a join
+     * voids it (the caller may have written new inputs behind the join) and every slot's first frame
+     * afterwards bins in a launch of its own.  crender_pipeline_bind always voids its slot. */
+    CRENDER_STATIC_INPUTS = 16u
 };
 
 CRENDER_API int crender_abi_version(void);
