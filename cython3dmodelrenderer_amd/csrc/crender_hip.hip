@@ -85,6 +85,14 @@ constexpr int kThreads = 256;           // 4 wavefronts per workgroup
 #ifndef CR_WPE32
 #define CR_WPE32 6
 #endif
+#ifndef CR_ITEM_PIXELS
+#define CR_ITEM_PIXELS 2
+#endif
+constexpr int kItemPixels = CR_ITEM_PIXELS;  // samples per work item of the per-pixel sweep of 16-pixel tiles
+#ifndef CR_ITEM_PIXELS32
+#define CR_ITEM_PIXELS32 2
+#endif
+constexpr int kItemPixels32 = CR_ITEM_PIXELS32;   // the same for the small-record batches of 32-pixel tiles
 constexpr uint32_t kPixelPathRecords = 8;   // k_raster<16>: batches this short go pixel-parallel
 constexpr uint32_t kNoTiles = 0xFFFFFFFFu;
 
@@ -1673,8 +1681,11 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
         constexpr bool per_pixel = TS == 16;   // always the per-pixel sweep
         constexpr bool either = TS == 32;      // counted both ways, the batch picks its sweep
         // wave-inclusive scan of the work counts
-        const uint32_t my_px = (uint32_t)(box_w(box_wh) * box_h(box_wh));
-        const uint32_t my_blocks = per_pixel ? my_px : (uint32_t)blocks_of(box_wh);
+        // (per-pixel work is counted in ITEMS of kItemPixels / kItemPixels32 x-neighbours of a box row)
+        const uint32_t my_px = (uint32_t)(((box_w(box_wh) + kItemPixels32 - 1) / kItemPixels32) * box_h(box_wh));
+        // (16-pixel tiles: an item is a PAIR of x-neighbours of a box row, see the sweep)
+        const uint32_t my_blocks = per_pixel ? (uint32_t)(((box_w(box_wh) + kItemPixels - 1) / kItemPixels) * box_h(box_wh))
+                                             : (uint32_t)blocks_of(box_wh);
         uint32_t incl = my_blocks, incl_px = my_px;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -1754,20 +1765,43 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                         const Rec16Regs R = load_rec16(&recs[r]);
                         const uint32_t xy = __float_as_uint(R.c.z);
                         const int bw = box_w(__float_as_uint(R.c.w));
-                        const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bw));
-                        const int x = (int)(xy & 0xFFFF) + ((int)i - dy * bw), y = (int)(xy >> 16) + dy;
-                        unsigned long long k;
-                        if (fragment16(R, x, y, k)) lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                        // kItemPixels samples per item — x-neighbours of one box row — share the
+                        // item's record search, its six LDS reads and its decode (a third of a
+                        // sample's instructions and most of an iteration's dependent LDS round
+                        // trips); a box width that is no multiple wastes part of an item per row.
+                        const int bwn = (bw + kItemPixels - 1) / kItemPixels;
+                        const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
+                        const int px0 = ((int)i - dy * bwn) * kItemPixels;
+                        const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
+                        unsigned long long *kp = &key[(y - Y0) * TS + (x - X0)];
+#pragma unroll
+                        for (int j = 0; j < kItemPixels; ++j) {
+                            unsigned long long k;
+                            if (fragment16(R, x + j, y, k) && (j == 0 || px0 + j < bw)) lds_key_min(kp + j, k);
+                        }
                     } else {
                         const uint32_t xy = q.box_xy[r];
                         const int bw = box_w(q.box_wh[r]);
-                        // i / bw for i < 1024, bw <= 32: the approximate reciprocal is exact enough
-                        const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bw));
-                        const int x = (int)(xy & 0xFFFF) + ((int)i - dy * bw), y = (int)(xy >> 16) + dy;
                         const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
                                        q.x2[r], q.y2[r], q.z2[r]};
-                        unsigned long long k;
-                        if (fragment(t, q.tri[r], x, y, k)) lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                        const uint32_t id = q.tri[r];
+                        // the item's samples share its record search, its twelve LDS reads, the nine
+                        // edge constants and the refined reciprocals (raster_math.h (2)): per sample
+                        // that was 150 vector instructions, a pair costs 175
+                        const TriSetup st = make_setup(t, kItemPixels32 > 1);
+                        const int bwn = (bw + kItemPixels32 - 1) / kItemPixels32;
+                        // i / bwn for i < 1024, bwn <= 32: the approximate reciprocal is exact enough
+                        const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
+                        const int px0 = ((int)i - dy * bwn) * kItemPixels32;
+                        const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
+                        unsigned long long *kp = &key[(y - Y0) * TS + (x - X0)];
+#pragma unroll
+                        for (int j = 0; j < kItemPixels32; ++j) {
+                            float n1, n2, n3;
+                            numerators(st, x + j, y, n1, n2, n3);
+                            unsigned long long k;
+                            if (fragment_from(st, id, n1, n2, n3, true, k) && (j == 0 || px0 + j < bw)) lds_key_min(kp + j, k);
+                        }
                     }
                 }
             };
