@@ -85,6 +85,9 @@ constexpr int kThreads = 256;           // 4 wavefronts per workgroup
 #ifndef CR_WPE32
 #define CR_WPE32 6
 #endif
+#ifndef CR_DPP_SCAN
+#define CR_DPP_SCAN 1
+#endif
 #ifndef CR_ITEM_PIXELS
 #define CR_ITEM_PIXELS 2
 #endif
@@ -986,6 +989,32 @@ CR_DEV void lds_key_min(unsigned long long *slot, unsigned long long k)
     __hip_atomic_fetch_min(slot, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Inclusive sum over the 64 lanes of a wavefront with DPP row shifts and row broadcasts (the
+// shape LLVM's atomic optimizer emits on gfx9): six vector adds, no LDS.  A scan built from
+// __shfl_up is six ds_bpermute round trips in a dependent chain, and the batch's scan sits on
+// every covered tile's critical path.
+CR_DEV uint32_t wave_incl_sum(uint32_t v)
+{
+#if CR_DPP_SCAN
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
+    return (uint32_t)x;
+#else
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+#endif
+}
+
 // One batch of (tile, triangle) work in LDS, struct-of-arrays, slot = thread index.
 // A record's pixel box (clipped to the tile) is cut into work items numbered row-major:
 // 4x4-pixel blocks on 32/64-pixel tiles, single pixels on 16-pixel tiles; blk_scan holds the
@@ -1376,12 +1405,7 @@ CR_DEV void build_order(const uint32_t *__restrict__ count, int ntx, int nty,
     uint32_t incl[5];
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
-        incl[c] = n[c];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t v = __shfl_up(incl[c], d, 64);
-            if (lane >= d) incl[c] += v;
-        }
+        incl[c] = wave_incl_sum(n[c]);
         if (lane == 63) scr[wave * 5 + c] = incl[c];
     }
     __syncthreads();
@@ -1686,16 +1710,9 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
         // (16-pixel tiles: an item is a PAIR of x-neighbours of a box row, see the sweep)
         const uint32_t my_blocks = per_pixel ? (uint32_t)(((box_w(box_wh) + kItemPixels - 1) / kItemPixels) * box_h(box_wh))
                                              : (uint32_t)blocks_of(box_wh);
-        uint32_t incl = my_blocks, incl_px = my_px;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t v = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += v;
-            if constexpr (either) {
-                const uint32_t vp = __shfl_up(incl_px, d, 64);
-                if (lane >= d) incl_px += vp;
-            }
-        }
+        const uint32_t incl = wave_incl_sum(my_blocks);
+        uint32_t incl_px = my_px;
+        if constexpr (either) incl_px = wave_incl_sum(my_px);
         // previous batch's sweeps must be over before the queue is overwritten; this
         // barrier also orders the key initialisation before the first sweep
         __syncthreads();
@@ -1863,12 +1880,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                     __syncthreads();
                     // survivors per record -> the same two-level prefix as the block counts
                     const uint32_t mine = (uint32_t)__popcll(q.mask[tid]);
-                    uint32_t inc = mine;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const uint32_t v = __shfl_up(inc, d, 64);
-                        if (lane >= d) inc += v;
-                    }
+                    const uint32_t inc = wave_incl_sum(mine);
                     q.blk_scan[tid] = inc - mine;
                     if (lane == 63) q.wave_blocks[wave] = inc;
                     __syncthreads();
