@@ -199,6 +199,41 @@ __global__ __launch_bounds__(kThreads) void k_clear(float *__restrict__ zb, floa
     }
 }
 
+// Minimum / maximum over the 64 lanes of a wavefront, left in every lane: DPP row shifts and row
+// broadcasts carry the running value to lane 63, one readlane hands it out (a butterfly of
+// __shfl_xor is six ds_swizzle / ds_bpermute round trips per value, in the middle of the binning
+// wavefronts' latency chain).
+#ifndef CR_DPP_REDUCE
+#define CR_DPP_REDUCE 1
+#endif
+template <bool MAX>
+CR_DEV int wave_reduce(int v)
+{
+#if CR_DPP_REDUCE
+    const int id = MAX ? (int)0x80000000 : 0x7FFFFFFF;
+    auto op = [](int a, int b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+    v = op(v, __builtin_amdgcn_update_dpp(id, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = op(v, __builtin_amdgcn_update_dpp(id, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = op(v, __builtin_amdgcn_update_dpp(id, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = op(v, __builtin_amdgcn_update_dpp(id, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = op(v, __builtin_amdgcn_update_dpp(id, v, 0x142, 0xa, 0xf, false));   // row_bcast:15
+    v = op(v, __builtin_amdgcn_update_dpp(id, v, 0x143, 0xc, 0xf, false));   // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+#else
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(v, d, 64);
+        v = MAX ? (v > o ? v : o) : (v < o ? v : o);
+    }
+    return v;
+#endif
+}
+CR_DEV void wave_box(int &X0, int &X1, int &Y0, int &Y1)
+{
+    X0 = wave_reduce<false>(X0); X1 = wave_reduce<true>(X1);
+    Y0 = wave_reduce<false>(Y0); Y1 = wave_reduce<true>(Y1);
+}
+
 // ---- binning ----------------------------------------------------------------------
 // Tile range of a triangle packed as tx0 | tx1 << 16 (x) and ty0 | ty1 << 16 (y),
 // inclusive; kNoTiles in .x marks a culled / empty triangle.  `bx`, `by` receive the pixel box
@@ -622,11 +657,7 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
     if (r.x != kNoTiles) {
         X0 = r.x & 0xFFFF; X1 = r.x >> 16; Y0 = r.y & 0xFFFF; Y1 = r.y >> 16;
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        X0 = min(X0, __shfl_xor(X0, d, 64)); X1 = max(X1, __shfl_xor(X1, d, 64));
-        Y0 = min(Y0, __shfl_xor(Y0, d, 64)); Y1 = max(Y1, __shfl_xor(Y1, d, 64));
-    }
+    wave_box(X0, X1, Y0, Y1);
     wave_lds_sync();        // projected vertices and entries visible to every lane
     CR_SETUP_STAMP(2);      // projected, ranges known
     if (PROJECT) stage_out<kWave>(proj_out + b0 * 9, sv, n * 9);
@@ -762,11 +793,7 @@ __global__ __launch_bounds__(kWave) void k_count_wave(const float *__restrict__ 
     if (r.x != kNoTiles) {
         X0 = r.x & 0xFFFF; X1 = r.x >> 16; Y0 = r.y & 0xFFFF; Y1 = r.y >> 16;
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        X0 = min(X0, __shfl_xor(X0, d, 64)); X1 = max(X1, __shfl_xor(X1, d, 64));
-        Y0 = min(Y0, __shfl_xor(Y0, d, 64)); Y1 = max(Y1, __shfl_xor(Y1, d, 64));
-    }
+    wave_box(X0, X1, Y0, Y1);
     __syncthreads();
     if (PROJECT) stage_out<kWave>(proj_out + b0 * 9, sv, n * 9);
     if (X1 < 0) return;     // nothing to count (uniform)
@@ -804,11 +831,7 @@ __global__ __launch_bounds__(kWave) void k_fill_wave(const uint2 *__restrict__ t
     if (r.x != kNoTiles) {
         X0 = r.x & 0xFFFF; X1 = r.x >> 16; Y0 = r.y & 0xFFFF; Y1 = r.y >> 16;
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        X0 = min(X0, __shfl_xor(X0, d, 64)); X1 = max(X1, __shfl_xor(X1, d, 64));
-        Y0 = min(Y0, __shfl_xor(Y0, d, 64)); Y1 = max(Y1, __shfl_xor(Y1, d, 64));
-    }
+    wave_box(X0, X1, Y0, Y1);
     if (X1 < 0) return;
     const int bw = X1 - X0 + 1, area = bw * (Y1 - Y0 + 1);
     if (area > kWaveHistTiles) {
