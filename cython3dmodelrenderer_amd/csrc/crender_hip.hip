@@ -85,6 +85,9 @@ constexpr int kThreads = 256;           // 4 wavefronts per workgroup
 #ifndef CR_WPE32
 #define CR_WPE32 6
 #endif
+#ifndef CR_SETUP_DIRECT
+#define CR_SETUP_DIRECT 1
+#endif
 #ifndef CR_DPP_SCAN
 #define CR_DPP_SCAN 1
 #endif
@@ -615,26 +618,38 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
     const int64_t b0 = group * kWave;
     const int n = (int)((T - b0) < kWave ? (T - b0) : kWave);
     CR_SETUP_STAMP(0);
-    stage_in<kWave>(tri_in + b0 * 9, sv, n * 9);
+    // (CR_SETUP_DIRECT: each lane loads and stores its own 36-byte record — every byte of every line
+    // is some lane's — instead of going through an LDS staging buffer: one LDS round trip and a
+    // wait less in a kernel that is a chain of waits)
+    if (!CR_SETUP_DIRECT) stage_in<kWave>(tri_in + b0 * 9, sv, n * 9);
     // only the normals' z components are needed (.pyx:202): three strided loads per lane
     float nz0 = 0.0f, nz1 = 0.0f, nz2 = 0.0f;
+    float a[9] = {};
     if (lane < n) {
+        if (CR_SETUP_DIRECT) load9(tri_in + (b0 + lane) * 9, a);
         const float *nn = nrm + (b0 + lane) * 9;
         nz0 = nn[2]; nz1 = nn[5]; nz2 = nn[8];
     }
-    wave_lds_sync();
+    if (!CR_SETUP_DIRECT) wave_lds_sync();
     CR_SETUP_STAMP(1);      // inputs staged
     uint2 r = make_uint2(kNoTiles, 0);
     if (lane < n) {
         float *v = sv + lane * 9;
-        float a[9];
+        if (!CR_SETUP_DIRECT) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) a[i] = v[i];
+            for (int i = 0; i < 9; ++i) a[i] = v[i];
+        }
         if (PROJECT) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) project_vertex(P, a + 3 * c);
+            if (CR_SETUP_DIRECT) {
+                float *o = proj_out + (b0 + lane) * 9;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) v[i] = a[i];
+                for (int i = 0; i < 9; ++i) o[i] = a[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) v[i] = a[i];
+            }
         }
         uint32_t bx = 0, by = 0;
         const TriXYZ t{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]};
@@ -660,7 +675,7 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
     wave_box(X0, X1, Y0, Y1);
     wave_lds_sync();        // projected vertices and entries visible to every lane
     CR_SETUP_STAMP(2);      // projected, ranges known
-    if (PROJECT) stage_out<kWave>(proj_out + b0 * 9, sv, n * 9);
+    if (PROJECT && !CR_SETUP_DIRECT) stage_out<kWave>(proj_out + b0 * 9, sv, n * 9);
     if (X1 < 0) return;     // nothing to bin (uniform)
     const int bw = X1 - X0 + 1, area = bw * (Y1 - Y0 + 1);
     if (area > kWaveHistTiles) {
