@@ -618,6 +618,10 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
     const int64_t b0 = group * kWave;
     const int n = (int)((T - b0) < kWave ? (T - b0) : kWave);
     CR_SETUP_STAMP(0);
+    // the histogram is zeroed whole while the inputs are on their way (it used to be zeroed, as far
+    // as needed, between the bounding box and pass A: one more wait in the chain)
+#pragma unroll
+    for (int i = 0; i < kWaveHistTiles / kWave; ++i) hist[i * kWave + lane] = 0;
     // (CR_SETUP_DIRECT: each lane loads and stores its own 36-byte record — every byte of every line
     // is some lane's — instead of going through an LDS staging buffer: one LDS round trip and a
     // wait less in a kernel that is a chain of waits)
@@ -682,8 +686,6 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
         bin_direct_append<NP>(r, img, G.ntx, count, bins, dcap, hdr, hv);
         return;
     }
-    for (int i = lane; i < area; i += kWave) hist[i] = 0;
-    wave_lds_sync();
     for_each_tile_xy(r, [&](int tx, int ty, int) { atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u); });
     wave_lds_sync();
     CR_SETUP_STAMP(3);      // pass A done
@@ -782,6 +784,8 @@ __global__ __launch_bounds__(kWave) void k_count_wave(const float *__restrict__ 
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     const int n = (int)((T - b0) < kWave ? (T - b0) : kWave);
     stage_in<kWave>(tri_in + b0 * 9, sv, n * 9);
+#pragma unroll
+    for (int i = 0; i < kWaveHistTiles / kWave; ++i) hist[i * kWave + lane] = 0;   // (while the inputs are on their way)
     float nz0 = 0.0f, nz1 = 0.0f, nz2 = 0.0f;      // .pyx:202 looks at the normals' z only
     if (lane < n) {
         const float *nn = nrm + (b0 + lane) * 9;
@@ -817,8 +821,6 @@ __global__ __launch_bounds__(kWave) void k_count_wave(const float *__restrict__ 
         for_each_tile(r, 0u, G.ntx, [&](int tile, uint32_t) { atomicAdd(&count[tile], 1u); });
         return;
     }
-    for (int i = lane; i < area; i += kWave) hist[i] = 0;
-    __syncthreads();
     for_each_tile_xy(r, [&](int tx, int ty, int) { atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u); });
     __syncthreads();
     const float rbw = 1.0f / (float)bw;
@@ -842,6 +844,8 @@ __global__ __launch_bounds__(kWave) void k_fill_wave(const uint2 *__restrict__ t
     const int lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     uint2 r = (b0 + lane < T) ? trange[b0 + lane] : make_uint2(kNoTiles, 0);
+#pragma unroll
+    for (int i = 0; i < kWaveHistTiles / kWave; ++i) hist[i * kWave + lane] = 0;   // (while the ranges are on their way)
     int X0 = 0x7FFFFFFF, X1 = -1, Y0 = 0x7FFFFFFF, Y1 = -1;
     if (r.x != kNoTiles) {
         X0 = r.x & 0xFFFF; X1 = r.x >> 16; Y0 = r.y & 0xFFFF; Y1 = r.y >> 16;
@@ -856,7 +860,6 @@ __global__ __launch_bounds__(kWave) void k_fill_wave(const uint2 *__restrict__ t
         });
         return;
     }
-    for (int i = lane; i < area; i += kWave) hist[i] = 0;
     __syncthreads();
     for_each_tile_xy(r, [&](int tx, int ty, int) { atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u); });
     __syncthreads();
