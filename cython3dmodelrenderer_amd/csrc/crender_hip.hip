@@ -693,12 +693,16 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
         constexpr int kRounds = kWaveHistTiles / kWave;
         const float rbw = 1.0f / (float)bw;
         uint32_t c[kRounds], t[kRounds], base[kRounds];
+        const int nr = (area + kWave - 1) / kWave;      // rounds that have tiles at all (uniform; mostly 1)
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
-            const int i = k * kWave + lane;
-            c[k] = (k * kWave < area && i < area) ? hist[i] : 0u;
-            const int dy = (int)(((float)i + 0.5f) * rbw);          // exact: i < 2^22
-            t[k] = (uint32_t)((Y0 + dy) * G.ntx + X0 + (i - dy * bw));
+            c[k] = 0u; t[k] = 0u;
+            if (k < nr) {
+                const int i = k * kWave + lane;
+                c[k] = i < area ? hist[i] : 0u;
+                const int dy = (int)(((float)i + 0.5f) * rbw);          // exact: i < 2^22
+                t[k] = (uint32_t)((Y0 + dy) * G.ntx + X0 + (i - dy * bw));
+            }
         }
 #pragma unroll
         for (int k = 0; k < kRounds; ++k)
@@ -867,12 +871,16 @@ __global__ __launch_bounds__(kWave) void k_fill_wave(const uint2 *__restrict__ t
         constexpr int kRounds = kWaveHistTiles / kWave;
         const float rbw = 1.0f / (float)bw;
         uint32_t c[kRounds], t[kRounds], base[kRounds];
+        const int nr = (area + kWave - 1) / kWave;      // rounds that have tiles at all (uniform; mostly 1)
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
-            const int i = k * kWave + lane;
-            c[k] = (k * kWave < area && i < area) ? hist[i] : 0u;
-            const int dy = (int)(((float)i + 0.5f) * rbw);          // exact: i < 2^22
-            t[k] = (uint32_t)((Y0 + dy) * G.ntx + X0 + (i - dy * bw));
+            c[k] = 0u; t[k] = 0u;
+            if (k < nr) {
+                const int i = k * kWave + lane;
+                c[k] = i < area ? hist[i] : 0u;
+                const int dy = (int)(((float)i + 0.5f) * rbw);          // exact: i < 2^22
+                t[k] = (uint32_t)((Y0 + dy) * G.ntx + X0 + (i - dy * bw));
+            }
         }
 #pragma unroll
         for (int k = 0; k < kRounds; ++k)                            // all in flight together
