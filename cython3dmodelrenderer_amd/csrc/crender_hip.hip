@@ -85,6 +85,9 @@ constexpr int kThreads = 256;           // 4 wavefronts per workgroup
 #ifndef CR_WPE32
 #define CR_WPE32 6
 #endif
+#ifndef CR_ADDR32
+#define CR_ADDR32 1
+#endif
 #ifndef CR_SETUP_DIRECT
 #define CR_SETUP_DIRECT 1
 #endif
@@ -1151,13 +1154,14 @@ CR_DEV bool fragment16(const Rec16Regs &R, int X, int Y, unsigned long long &key
 // constants and reciprocals are there already) and colour / normal gathered by triangle index:
 // the operations of shade_and_store on the same inputs (.pyx:219, 226-242), without its gather
 // of the projected vertices and its nine edge constants.
+template <typename I>
 CR_DEV void shade16_store(const Rec16Regs &R, const float *__restrict__ col, const float *__restrict__ nrm,
-                          uint32_t tri, int X, int Y, size_t pix,
+                          uint32_t tri, int X, int Y, I pix,
                           float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb, const Light &Lt)
 {
     float c[9], n[9];
-    load9(col + (size_t)tri * 9, c);
-    load9(nrm + (size_t)tri * 9, n);
+    load9(elem(col, (I)((I)tri * 9)), c);
+    load9(elem(nrm, (I)((I)tri * 9)), n);
     TriSetup s;
     s.x0 = R.a.x; s.y0 = R.a.y; s.x1 = R.a.z; s.y1 = R.a.w;
     s.x2 = R.b.x; s.y2 = R.b.y; s.z0 = R.b.z; s.z1 = R.b.w;
@@ -1374,6 +1378,7 @@ struct TileLists {
     uint32_t *heavy_flag, *heavy_slots, *heavy_ctr_next;
     int nhelp;                  // 3 * hmax helper workgroups
     // dispatch order (see build_order): null when the launch is not ordered
+    int addr32;                  // framebuffer and attribute byte offsets fit 32 bits (see elem())
     const uint32_t *order, *hint, *hint_bad;
     uint32_t *order_next, *hint_next, *hint_bad_next;
     unsigned char *grouped_next;
@@ -2012,19 +2017,22 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     // resolve: every pixel of the rectangle is written at most once (exactly once if CLEAR).
     // A part's pixels are taken by the first wavefronts in rows of its own width.
     const int npx = quad >= 0 ? rw * (TS / 2) : TS * TS;
+    auto resolve = [&](auto index_tag) {
+    using I = decltype(index_tag);
     for (int p0 = tid; p0 < npx; p0 += kThreads) {
         const int dy = rw == TS ? p0 / TS : p0 / (TS / 2), dx = p0 - dy * rw;
         const int x = X0 + dx, y = Y0 + dy;
         if (x >= X1 || y >= Y1) continue;
         const int p = dy * TS + dx;
-        const size_t pix = (size_t)y * G.W + x;
+        const I pix = (I)((I)y * (I)G.W + (I)x);
         const uint32_t low = (uint32_t)key[p];
         if (low == KEY_LOW_PRIOR) {
             if (CLEAR) {
-                zb[pix] = 1e6f;
-                cb[pix * 3] = 0.0f; cb[pix * 3 + 1] = 0.0f; cb[pix * 3 + 2] = 0.0f;
-                nb[pix * 3] = 0.0f; nb[pix * 3 + 1] = 0.0f; nb[pix * 3 + 2] = 0.0f;
-                if (win) win[pix] = -1;
+                *elem(zb, pix) = 1e6f;
+                float *cp = elem(cb, (I)(pix * 3)), *np_ = elem(nb, (I)(pix * 3));
+                cp[0] = 0.0f; cp[1] = 0.0f; cp[2] = 0.0f;
+                np_[0] = 0.0f; np_[1] = 0.0f; np_[2] = 0.0f;
+                if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = -1;
             }
             continue;
         }
@@ -2035,19 +2043,22 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                 // the winner's record is still in LDS (it came with the last batch)
                 shade16_store(load_rec16(&recs[low & 0xFFu]), col, nrm, L.pos_of ? L.pos_of[id] : id, x, y, pix,
                               zb, cb, nb, L.light);
-                if (win) win[pix] = (int32_t)id;
+                if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = (int32_t)id;
                 continue;
             }
         }
         if (dbg & 2) {   // ablation: no shading (development build)
-            zb[pix] = (float)id;
-            cb[pix * 3] = 1.0f; cb[pix * 3 + 1] = 1.0f; cb[pix * 3 + 2] = 1.0f;
-            nb[pix * 3] = 1.0f; nb[pix * 3 + 1] = 1.0f; nb[pix * 3 + 2] = 1.0f;
+            *elem(zb, pix) = (float)id;
+            float *cp = elem(cb, (I)(pix * 3)), *np_ = elem(nb, (I)(pix * 3));
+            cp[0] = 1.0f; cp[1] = 1.0f; cp[2] = 1.0f;
+            np_[0] = 1.0f; np_[1] = 1.0f; np_[2] = 1.0f;
             continue;
         }
         shade_and_store(proj, col, nrm, L.pos_of ? L.pos_of[id] : id, x, y, pix, zb, cb, nb, L.light);
-        if (win) win[pix] = (int32_t)id;
+        if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = (int32_t)id;
     }
+    };
+    if (L.addr32) resolve(uint32_t{}); else resolve(size_t{});
     CR_STAMP(3);
 #ifdef CRENDER_STAMPS
     if (g_stamps && threadIdx.x == 0) g_stamps[stamp_base + 11] = __builtin_amdgcn_s_memtime();
@@ -2723,6 +2734,8 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     tl.grouped_next = ordered ? plan->grouped(hp ^ 1) : nullptr;
     tl.hint_bad = plan->hdr() + 5 + par;
     tl.hint_bad_next = plan->hdr() + 5 + (par ^ 1);
+    tl.addr32 = CR_ADDR32 && (uint64_t)G.H * (uint64_t)G.W * 12ull < (1ull << 32) &&
+                (uint64_t)(plan->last_T > 0 ? plan->last_T : 1) * 36ull < (1ull << 32);
     if (ordered) plan->hint_par = hp ^ 1;
     const uintptr_t any = (uintptr_t)d_z | (uintptr_t)d_color | (uintptr_t)d_normal | (uintptr_t)d_winner;
     tl.vec_clear = (any & 15u) == 0 && (G.W & 3) == 0;

@@ -319,13 +319,32 @@ CR_DEV float guro_factor(const Light &L, float n0, float n1, float n2)
     return f;
 }
 
+// Element `idx` of an array whose base is the same for the whole wavefront.  With a 32-bit index
+// type the address is base + a 32-BIT BYTE OFFSET (the caller guarantees idx * 4 < 2^32): the
+// compiler then keeps the base in scalar registers and the per-lane part in one vector register,
+// instead of 64-bit vector arithmetic per access (v_mad_u64_u32, v_lshl_add_u64).  Worth 1 % of
+// bunny 4096^2's vector instructions and of its raster launch, where the vector pipes are the bound.
+template <typename I>
+CR_DEV float *elem(float *base, I idx)
+{
+    if constexpr (sizeof(I) == 4) return reinterpret_cast<float *>(reinterpret_cast<char *>(base) + (uint32_t)(idx * 4u));
+    else return base + idx;
+}
+template <typename I>
+CR_DEV const float *elem(const float *base, I idx)
+{
+    if constexpr (sizeof(I) == 4) return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (uint32_t)(idx * 4u));
+    else return base + idx;
+}
+
 // z, colour and normal of a fragment from its barycentrics and the triangle's attributes
 // (.pyx:219, 226-242), with the optional fused illumination.
+template <typename I>
 CR_DEV void store_fragment(float z, const float c[9], const float n[9], float b1, float b2, float b3,
-                           const Light &L, size_t pix, float *__restrict__ zb, float *__restrict__ cb,
+                           const Light &L, I pix, float *__restrict__ zb, float *__restrict__ cb,
                            float *__restrict__ nb)
 {
-    zb[pix] = z;
+    *elem(zb, pix) = z;
     float c0 = interp(c[0], c[3], c[6], b1, b2, b3);
     float c1 = interp(c[1], c[4], c[7], b1, b2, b3);
     float c2 = interp(c[2], c[5], c[8], b1, b2, b3);
@@ -336,7 +355,7 @@ CR_DEV void store_fragment(float z, const float c[9], const float n[9], float b1
         const float f = guro_factor(L, n0, n1, n2);
         c0 *= f; c1 *= f; c2 *= f;
     }
-    float *cp = cb + pix * 3, *np_ = nb + pix * 3;
+    float *cp = elem(cb, (I)(pix * 3)), *np_ = elem(nb, (I)(pix * 3));
     cp[0] = c0; cp[1] = c1; cp[2] = c2;
     np_[0] = n0; np_[1] = n1; np_[2] = n2;
 }
@@ -344,15 +363,16 @@ CR_DEV void store_fragment(float z, const float c[9], const float n[9], float b1
 // Recompute the winning fragment of pixel (X, Y) and store z, colour, normal
 // (.pyx:219, 226-242).  Same device functions as the coverage pass, so z is the very
 // value the key was built from.
+template <typename I>
 CR_DEV void shade_and_store(const float *__restrict__ proj, const float *__restrict__ col,
                             const float *__restrict__ nrm, uint32_t tri, int X, int Y,
-                            size_t pix, float *__restrict__ zb, float *__restrict__ cb,
+                            I pix, float *__restrict__ zb, float *__restrict__ cb,
                             float *__restrict__ nb, const Light &L = Light{0.f, 0.f, 0.f, 0})
 {
-    const TriXYZ t = load_tri(proj + (size_t)tri * 9);
+    const TriXYZ t = load_tri(elem(proj, (I)((I)tri * 9)));
     float c[9], n[9];
-    load9(col + (size_t)tri * 9, c);
-    load9(nrm + (size_t)tri * 9, n);
+    load9(elem(col, (I)((I)tri * 9)), c);
+    load9(elem(nrm, (I)((I)tri * 9)), n);
     float b1, b2, b3;
     barycentric(t, X, Y, b1, b2, b3);
     store_fragment(interp(t.z0, t.z1, t.z2, b1, b2, b3), c, n, b1, b2, b3, L, pix, zb, cb, nb);
