@@ -1729,7 +1729,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             const uint32_t left = end - base;
             const uint32_t pix_max = (dbg >> 16) & 0xFF ? (uint32_t)((dbg >> 16) & 0xFF) - 1u : kPixelPathRecords;
             if (left <= pix_max) {
-                __syncthreads();
+                if (base != beg) __syncthreads();
                 if (tid < (int)left) put_rec16(&recs[tid], cur_t, key_low, box_xy, box_wh);
                 __syncthreads();
 #ifdef CRENDER_STAMPS
@@ -1767,9 +1767,9 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
         const uint32_t incl = wave_incl_sum(my_blocks);
         uint32_t incl_px = my_px;
         if constexpr (either) incl_px = wave_incl_sum(my_px);
-        // previous batch's sweeps must be over before the queue is overwritten; this
-        // barrier also orders the key initialisation before the first sweep
-        __syncthreads();
+        // previous batch's sweeps must be over before the queue is overwritten (the first batch has
+        // none before it: the barrier behind the queue orders the key initialisation too)
+        if (base != beg) __syncthreads();
         if constexpr (TS == 16) {
             if (tid < kBatch) put_rec16(&recs[tid], cur_t, key_low, box_xy, box_wh);
             scan16[tid] = incl - my_blocks;
