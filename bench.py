@@ -18,11 +18,17 @@ N > 1 (launched by torch.distributed.run, one rank per GPU), two modes:
   --mode frames            every rank renders its own full frames, no collective in the data
                            path: "weak" scaling, value = frames of all ranks per second.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the raster kernel against HBM bandwidth
-with the algorithmic bytes of SURVEY.md section 8d (108 B per triangle read once + 28 B per
-pixel written once); its launch duration is measured with HIP events on the frame's own
-stream.  `cpu_baseline` times the CPU oracle in its Version-C shape (OpenMP dynamic loop +
-per-pixel locks) on this host — a reported baseline, not the target.
+Rank 0 prints ONE JSON line.  `roofline` prices the kernel that rasterizes the timed region's
+frames — `k_frame` (raster pass + the next frame's binning wavefronts in one launch) when the
+swap chain runs with look-ahead, else `k_raster` — against HBM bandwidth with the algorithmic
+bytes of SURVEY.md section 8d (108 B per triangle read once + 28 B per pixel written once); its
+launch duration is measured with HIP events on the frame's own stream in a pass of its own
+(frames one after another on ONE stream, so that a launch's duration is its own), and is never
+taken shorter than the back-to-back frame time of that pass or the committed rocprofv3 average
+(profiles/kernel_avg.json).  `cpu_baseline` times the CPU oracle in its Version-C shape (OpenMP
+dynamic loop + per-pixel locks) on this host — a reported baseline, not the target; `api_call`
+times the reference's own calls (`render_model(model)` from numpy arrays, the getters,
+`Renderer.render`) through the drop-in classes, PCIe included, beside the oracle's same calls.
 """
 import argparse
 import json
@@ -48,6 +54,18 @@ def load_traffic(workload):
     try:
         with open(path) as fh:
             return json.load(fh).get(workload, {}).get("raster_hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def load_rocprof_avg_ms(workload, kernel):
+    """Average launch duration (ms) of `kernel` in the committed rocprofv3 kernel trace of this
+    workload's bench command (profiles/kernel_avg.json, made by scripts/summarize_prof.py), if any."""
+    path = os.path.join(ROOT, "profiles", "kernel_avg.json")
+    try:
+        with open(path) as fh:
+            ns = json.load(fh).get(workload, {}).get(kernel)
+        return None if ns is None else float(ns) * 1e-6
     except Exception:
         return None
 
@@ -100,6 +118,67 @@ def cpu_baseline(tri, col, nrm, H, W, fov, budget_s=12.0):
                       f"OpenMP dynamic schedule + per-pixel locks, {threads} threads"}
 
 
+class _Model:
+    """What the reference's filler reads off a Model (.pyx:94-96)."""
+
+    def __init__(self, tri, col, nrm):
+        self._vertices_by_triangles, self._colors_by_triangles, self._normals_by_triangles = tri, col, nrm
+
+
+def api_calls(tri, col, nrm, H, W, fov, device, budget_s=6.0):
+    """The reference's OWN calls through the drop-in classes, model arrays in host numpy memory,
+    results in host numpy memory where the reference returns them there — PCIe included:
+      render_model(model)                       .pyx:92-104 (upload + K1 + K2, buffers composite)
+      render_model(model); get_color_buffer()   .pyx:249 on top
+      Renderer.render(model)                    cy/renderer.py:47-49 with GuroIllumination
+    each beside the CPU oracle's same call sequence on min(16, ncpu) threads."""
+    import torch
+    from cython3dmodelrenderer_amd import Renderer
+    from cython3dmodelrenderer_amd.illumination import GuroIllumination
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    from oracle import oracle as O
+    m = _Model(tri, col, nrm)
+    light = GuroIllumination([0, 0, 1])
+
+    def timed(call, sync, budget=budget_s):
+        call(); call(); sync()                  # warm-up: plans, pinned buffers, staging
+        t0 = time.perf_counter()
+        call(); sync()
+        one = time.perf_counter() - t0
+        n = int(max(3, min(200, budget / max(one, 1e-5))))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            call()
+        sync()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def dsync():
+        torch.cuda.synchronize(device)
+
+    out = {"unit": "ms per call", "model_arrays": "host numpy, uploaded by every call (as the reference copies them)"}
+    f = AdvancedPixelBufferFiller(H, W, fov=fov, device=device)
+    out["render_model_ms"] = timed(lambda: f.render_model(m), dsync)
+    out["render_model_plus_color_ms"] = timed(lambda: (f.render_model(m), f.get_color_buffer()), dsync)
+    f3 = AdvancedPixelBufferFiller(H, W, fov=fov, device=device)
+    out["render_model_plus_three_buffers_ms"] = timed(
+        lambda: (f3.render_model(m), f3.get_color_buffer(), f3.get_normals_buffer(), f3.get_z_buffer()), dsync)
+    for name, mode in (("numpy_illumination", False), ("default", None), ("on_device", True), ("fused", "fused")):
+        r = Renderer(AdvancedPixelBufferFiller(H, W, fov=fov, device=device), light, None, H, W, on_device=mode)
+        out[f"renderer_render_{name}_ms"] = timed(lambda: r.render(m), dsync)
+    threads = min(16, os.cpu_count() or 1)
+    of = O.OracleFiller(H, W, fov=fov, n_threads=threads, mode="omp")
+    cpu = {"threads": threads}
+    cpu["render_model_ms"] = timed(lambda: of.render_model(m), lambda: None, budget_s / 2)
+
+    def cpu_render():
+        of.render_model(m)
+        light.draw_illumination(of.color_buffer, of.normals_buffer)
+        return of.color_buffer
+    cpu["renderer_render_ms"] = timed(cpu_render, lambda: None, budget_s / 2)
+    out["cpu_oracle"] = cpu
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +193,8 @@ def main():
     ap.add_argument("--max-triangles", type=int, default=-1,
                     help="experiment knob: keep only the first N triangles (0 = pure clear)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api-calls", action="store_true",
+                    help="skip the api_call block (the reference's own calls, PCIe included)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the next frame's bin pass with this frame's raster pass")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
@@ -260,13 +341,47 @@ def main():
     need, cap = filler.bin_usage()
     assert need <= cap, "bin lists overflowed inside the timing pass"
 
+    # ---- the kernel of the timed region.  With look-ahead the swap chain's frames are ONE launch
+    # each, k_frame (this frame's raster workgroups + the next frame's binning wavefronts), not the
+    # k_setup_wave -> k_raster pair timed above.  Its duration is its own only when launches do not
+    # overlap: a chain of depth 1 (same kernel, same arguments, frames one after another on one
+    # stream), K frames back to back on the wall clock and K frames with HIP events around each launch.
+    lookahead = filler._pipe is not None and filler._pipe.lookahead
+    kframe_events_ms = kframe_b2b_ms = None
+    if lookahead:
+        probe = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile, pipeline=True,
+                                          pipeline_depth=1, lookahead=True,
+                                          row_strip=(y0, y1) if strips else None)
+        probe.render_arrays(tri, col, nrm, clear=True)
+        probe.synchronize()
+        for _ in range(max(3, args.warmup)):
+            probe.render_frame()
+        probe.synchronize()
+        assert probe._pipe.lookahead
+        barrier()
+        t4 = time.perf_counter()
+        for _ in range(args.steps):
+            probe.render_frame()
+        probe.join()
+        barrier()
+        kframe_b2b_ms = (time.perf_counter() - t4) / args.steps * 1e3
+        probe._pipe.timing_begin(args.steps)
+        for _ in range(args.steps):
+            probe.render_frame()
+        n_k, kframe_events_ms = probe._pipe.timing_end()
+        assert n_k == args.steps and not probe._pipe.overflowed(probe)
+        del probe
+
     if world > 1:
-        t = torch.tensor([elapsed, raster_ms, bin_ms, elapsed_render_only or 0.0], dtype=torch.float64,
+        t = torch.tensor([elapsed, raster_ms, bin_ms, elapsed_render_only or 0.0, kframe_events_ms or 0.0,
+                          kframe_b2b_ms or 0.0], dtype=torch.float64,
                          device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, raster_ms, bin_ms, ero = (float(v) for v in t.cpu())
+        elapsed, raster_ms, bin_ms, ero, ke, kb = (float(v) for v in t.cpu())
         if elapsed_render_only is not None:
             elapsed_render_only = ero
+        if lookahead:
+            kframe_events_ms, kframe_b2b_ms = ke, kb
 
     if rank == 0:
         frames_per_step = 1 if (world == 1 or strips) else world
@@ -283,7 +398,19 @@ def main():
         # The roofline uses the LONGER of the two, i.e. never the flattering one.
         single_ms = elapsed_single / args.steps * 1e3
         raster_b2b_ms = max(single_ms - bin_ms, 0.0)
-        launch_ms = max(raster_ms, raster_b2b_ms)
+        ts = filler.tile or (16 if H * W <= 1024 * 1024 else 32)
+        if lookahead:
+            kernel = f"k_frame<{ts},true>"
+            views = {"hip_events_around_each_launch": kframe_events_ms, "frames_back_to_back_on_one_stream": kframe_b2b_ms}
+            prof = load_rocprof_avg_ms(args.workload, "k_frame_one_stream") if rows == H else None
+        else:
+            kernel = f"k_raster<{ts},true>"
+            views = {"hip_events_around_each_launch": raster_ms,
+                     "single_stream_frame_minus_event_measured_bin_passes": raster_b2b_ms}
+            prof = load_rocprof_avg_ms(args.workload, "k_raster") if rows == H else None
+        if prof is not None:
+            views["committed_rocprofv3_average"] = prof
+        launch_ms = max(v for v in views.values() if v is not None)
         achieved = abytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         out = {
             "metric": "frames/sec", "value": fps, "unit": "frames/s",
@@ -324,20 +451,31 @@ def main():
                           "how": "HIP events on the frame's stream, second pass of K steps",
                           "ms_per_step_with_events": elapsed_events / args.steps * 1e3},
             "ms_per_frame_single_stream": elapsed_single / args.steps * 1e3,
-            "roofline": {"kernel": "k_raster", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": kernel, "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": abytes,
                          "avg_launch_ms": launch_ms,
-                         "avg_launch_ms_how": "max(HIP events around the launch, single-stream frame "
-                                              "time minus event-measured bin passes)",
+                         "avg_launch_ms_views": views,
+                         "avg_launch_ms_how": "the LONGEST of the views: the kernel the timed region's frames "
+                                              "run, launches one after another on one stream",
+                         # what the overlapped stream of frames achieves with the same launches
+                         "overlapped_frames_gbps": abytes * (args.steps / elapsed) / 1e9,
                          # PMC bytes of the committed profile are per WHOLE-frame launch: a strip's
                          # launch was not profiled
                          "traffic": load_traffic(args.workload) if rows == H else None},
             "bin_entries": {"needed": need, "capacity": cap},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if args.workload == "synth10m":
+            out["config"]["resident_model"] = (
+                "sorted ONCE at upload into tile-coherent order (Morton code of the 32-pixel tile of each "
+                "triangle's projected centroid: key kernel + device radix sort + three gathers, about 1 GB of "
+                "traffic, ~2 ms, outside the timed region); depth ties and the winner plane keep the caller's indices")
+        if not args.no_cpu_baseline:
+            # (rank 0, beside every N: the other ranks wait at the closing barrier meanwhile)
             out["cpu_baseline"] = cpu_baseline(tri, col, nrm, H, W, fov)
             out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
+        if not args.no_api_calls and world == 1 and H * W <= 4096 * 4096 and T <= 1_000_000:
+            out["api_call"] = api_calls(tri, col, nrm, H, W, fov, device)
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -10,7 +10,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK, EINVAL, EHIP, ENOMEM = 0, 1, 2, 3
 FUSED_CLEAR = 1
 NO_DIRECT_BINS = 2
@@ -50,6 +50,8 @@ SIGNATURES = {
     "crender_pipeline_join": (_i32, [_vp, _vp]),
     "crender_pipeline_bind": (_i32, [_vp, _i32, _vp, _vp, _vp, _i64, _f32p, _vp, _vp, _vp, _vp, _u32]),
     "crender_pipeline_submit": (_i32, [_vp, _vp]),
+    "crender_pipeline_timing_begin": (_i32, [_vp, _i32]),
+    "crender_pipeline_timing_end": (_i32, [_vp, C.POINTER(_i32), C.POINTER(C.c_double)]),
     "crender_atomic_scratch_bytes": (_sz, [_i32, _i32]),
     "crender_raster_atomic": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                      _u32, _vp, _vp]),

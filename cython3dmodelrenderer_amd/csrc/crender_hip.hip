@@ -29,7 +29,7 @@
 //   block, 8192 large-record sweep for every batch (32/64-pixel tiles), bits 16..23 = n + 1:
 //   pixel-parallel path of 16-pixel tiles for batches <= n records (n = 0 disables it; default
 //   kPixelPathRecords), 16384 frames of a swap chain are treated as lone frames (ordered dispatch
-//   and split tiles although they overlap).
+//   and split tiles although they overlap), 32768 no pixel-owner sweep on 32-pixel tiles.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -79,29 +79,9 @@ constexpr int kThreads = 256;           // 4 wavefronts per workgroup
 // CU instead of 5: bunny 4096^2 +5 %, T-Rex 8192^2 raster 0.381 -> 0.341 ms; the fused-clear
 // instantiation fits without spilling, the compositing one spills 4 registers).  The 64-pixel
 // kernel is limited by its 48 KB of LDS, not by registers.  (r01 A/B, same box.)
-#ifndef CR_WPE16
-#define CR_WPE16 7
-#endif
-#ifndef CR_WPE32
-#define CR_WPE32 6
-#endif
-#ifndef CR_ADDR32
-#define CR_ADDR32 1
-#endif
-#ifndef CR_SETUP_DIRECT
-#define CR_SETUP_DIRECT 1
-#endif
-#ifndef CR_DPP_SCAN
-#define CR_DPP_SCAN 1
-#endif
-#ifndef CR_ITEM_PIXELS
-#define CR_ITEM_PIXELS 2
-#endif
-constexpr int kItemPixels = CR_ITEM_PIXELS;  // samples per work item of the per-pixel sweep of 16-pixel tiles
-#ifndef CR_ITEM_PIXELS32
-#define CR_ITEM_PIXELS32 2
-#endif
-constexpr int kItemPixels32 = CR_ITEM_PIXELS32;   // the same for the small-record batches of 32-pixel tiles
+constexpr int kWavesPerSimd16 = 7, kWavesPerSimd32 = 6;   // (32-pixel tiles: 28.7 KB of LDS = 5 workgroups per CU)
+constexpr int kItemPixels = 2;      // samples per work item of the per-pixel sweep of 16-pixel tiles
+constexpr int kItemPixels32 = 2;    // the same for the small-record batches of 32-pixel tiles
 constexpr uint32_t kPixelPathRecords = 8;   // k_raster<16>: batches this short go pixel-parallel
 constexpr uint32_t kNoTiles = 0xFFFFFFFFu;
 
@@ -209,13 +189,9 @@ __global__ __launch_bounds__(kThreads) void k_clear(float *__restrict__ zb, floa
 // broadcasts carry the running value to lane 63, one readlane hands it out (a butterfly of
 // __shfl_xor is six ds_swizzle / ds_bpermute round trips per value, in the middle of the binning
 // wavefronts' latency chain).
-#ifndef CR_DPP_REDUCE
-#define CR_DPP_REDUCE 1
-#endif
 template <bool MAX>
 CR_DEV int wave_reduce(int v)
 {
-#if CR_DPP_REDUCE
     const int id = MAX ? (int)0x80000000 : 0x7FFFFFFF;
     auto op = [](int a, int b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
     v = op(v, __builtin_amdgcn_update_dpp(id, v, 0x111, 0xf, 0xf, false));   // row_shr:1
@@ -225,14 +201,6 @@ CR_DEV int wave_reduce(int v)
     v = op(v, __builtin_amdgcn_update_dpp(id, v, 0x142, 0xa, 0xf, false));   // row_bcast:15
     v = op(v, __builtin_amdgcn_update_dpp(id, v, 0x143, 0xc, 0xf, false));   // row_bcast:31
     return __builtin_amdgcn_readlane(v, 63);
-#else
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int o = __shfl_xor(v, d, 64);
-        v = MAX ? (v > o ? v : o) : (v < o ? v : o);
-    }
-    return v;
-#endif
 }
 CR_DEV void wave_box(int &X0, int &X1, int &Y0, int &Y1)
 {
@@ -482,8 +450,12 @@ CR_DEV void bin_direct_append(uint2 r_keep, const float4 *img, int ntx,
                               uint32_t dcap, uint32_t *__restrict__ hdr, const HeavyReg hv)
 {
     const int lane = threadIdx.x & 63;
-    // A lane's returning atomics are independent of each other: issue them all, then
-    // store (a loop of "atomic, wait, store" would pay one memory round trip per tile).
+    char *const bin_bytes = reinterpret_cast<char *>(bins);      // (slab <= kDirectBinBytes: 32-bit offsets)
+    auto entry_at = [&](uint32_t tile, uint32_t slot) {
+        return reinterpret_cast<float4 *>(bin_bytes + (uint32_t)((tile * dcap + slot) * (uint32_t)sizeof(BinEntry)));
+    };
+    // A lane's returning atomics are independent of each other: kPassC of them are issued, then their
+    // entries stored (a loop of "atomic, wait, store" would pay one memory round trip per tile).
     {
         int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
         if (r_keep.x != kNoTiles) {
@@ -491,23 +463,28 @@ CR_DEV void bin_direct_append(uint2 r_keep, const float4 *img, int ntx,
         }
         const int wd = tx1 - tx0 + 1, cnt = wd * (ty1 - ty0 + 1);
         if (cnt <= kWideTiles) {
-            uint32_t slot[kWideTiles];
+            constexpr int kPassC = 4;
             int cx = 0, rowbase = ty0 * ntx + tx0;    // tile k of the range, stepped
+#pragma unroll 1
+            for (int k0 = 0; k0 < cnt; k0 += kPassC) {
+                uint32_t slot[kPassC], tile[kPassC];
+                bool on[kPassC];
 #pragma unroll
-            for (int k = 0; k < kWideTiles; ++k) {
-                slot[k] = k < cnt ? atomicAdd(&count[rowbase + cx], 1u) : 0u;
-                if (++cx == wd) { cx = 0; rowbase += ntx; }
-            }
-            cx = 0; rowbase = ty0 * ntx + tx0;
-#pragma unroll
-            for (int k = 0; k < kWideTiles; ++k) {
-                if (k < cnt) {
-                    if (slot[k] < dcap) put_entry<NP>(bins + ((size_t)(rowbase + cx) * dcap + slot[k]) * NP, img, lane);
-                    else atomicMax(&hdr[1], slot[k] + 1);
-                    if (hv.ctr && slot[k] == kHeavyAt - 1) register_heavy(hv, (uint32_t)(rowbase + cx));
-                    if (slot[k] == 0) first_entry_of(hv, (uint32_t)(rowbase + cx));
+                for (int k = 0; k < kPassC; ++k) {
+                    tile[k] = (uint32_t)(rowbase + cx);
+                    on[k] = k0 + k < cnt;
+                    slot[k] = on[k] ? atomicAdd(&count[tile[k]], 1u) : 0u;
+                    if (++cx == wd) { cx = 0; rowbase += ntx; }
                 }
-                if (++cx == wd) { cx = 0; rowbase += ntx; }
+#pragma unroll
+                for (int k = 0; k < kPassC; ++k) {
+                    if (on[k]) {
+                        if (slot[k] < dcap) put_entry<NP>(entry_at(tile[k], slot[k]), img, lane);
+                        else atomicMax(&hdr[1], slot[k] + 1);
+                        if (hv.ctr && slot[k] == kHeavyAt - 1) register_heavy(hv, tile[k]);
+                        if (slot[k] == 0) first_entry_of(hv, tile[k]);
+                    }
+                }
             }
             r_keep.x = kNoTiles;   // done; only wide ranges are left for the cooperative walk
         }
@@ -535,8 +512,7 @@ CR_DEV void bin_direct_append(uint2 r_keep, const float4 *img, int ntx,
         constexpr int kRound = 8;
         for (int base = 0; base < total; base += 64 * kRound) {    // uniform: every lane takes
             const int j0 = base + lane;                             // every trip (shuffles inside)
-            uint32_t slot[kRound], tile[kRound];
-            int who[kRound];
+            uint32_t slot[kRound], tw[kRound];      // tw = tile | owner lane << 20 (direct bins: < 2^16 tiles)
 #pragma unroll
             for (int u = 0; u < kRound; ++u) {
                 const int j = j0 + 64 * u;
@@ -549,17 +525,19 @@ CR_DEV void bin_direct_append(uint2 r_keep, const float4 *img, int ntx,
                 const int ox0 = __shfl(sx0, own, 64), oy0 = __shfl(sy0, own, 64);
                 const int i = j - (__shfl(incl, own, 64) - ocnt);   // tile number within the range
                 const int dy = (int)(((float)i + 0.5f) * (1.0f / (float)(ow > 0 ? ow : 1)));  // exact: i < 2^22
-                tile[u] = (uint32_t)((oy0 + dy) * ntx + ox0 + (i - dy * ow));
-                who[u] = own;
-                slot[u] = j < total ? atomicAdd(&count[tile[u]], 1u) : 0u;
+                const uint32_t tile = (uint32_t)((oy0 + dy) * ntx + ox0 + (i - dy * ow));
+                const bool want = j < total;
+                tw[u] = tile | ((uint32_t)own << 20) | (want ? 0x80000000u : 0u);       // (bit 31: entry wanted)
+                slot[u] = want ? atomicAdd(&count[tile], 1u) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < kRound; ++u) {
-                if (j0 + 64 * u < total) {
-                    if (slot[u] < dcap) put_entry<NP>(bins + ((size_t)tile[u] * dcap + slot[u]) * NP, img, who[u]);
+                if (tw[u] >> 31) {
+                    const uint32_t tile = tw[u] & 0xFFFFFu;
+                    if (slot[u] < dcap) put_entry<NP>(entry_at(tile, slot[u]), img, (int)((tw[u] >> 20) & 63u));
                     else atomicMax(&hdr[1], slot[u] + 1);
-                    if (hv.ctr && slot[u] == kHeavyAt - 1) register_heavy(hv, tile[u]);
-                    if (slot[u] == 0) first_entry_of(hv, tile[u]);
+                    if (hv.ctr && slot[u] == kHeavyAt - 1) register_heavy(hv, tile);
+                    if (slot[u] == 0) first_entry_of(hv, tile);
                 }
             }
         }
@@ -594,8 +572,7 @@ struct SetupArgs {
     ProjConst P;
     Geom G;
 };
-constexpr size_t kSetupWaveLds = sizeof(float) * kWave * 9 + sizeof(float4) * kWave * kEntryPieces +
-                                 sizeof(uint32_t) * kWaveHistTiles;
+constexpr size_t kSetupWaveLds = sizeof(float4) * kWave * kEntryPieces + sizeof(uint32_t) * kWaveHistTiles;
 // The binning wavefront's lanes talk through LDS among themselves only: its "barrier" is the LDS
 // queue's own order (a wavefront's LDS operations complete in issue order) made explicit to the
 // compiler and to the wait counters — no s_barrier, so that the same code can run as one wavefront
@@ -614,9 +591,8 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
                             int64_t group, unsigned char *lds)
 {
     constexpr int NP = kEntryPieces;                         // 16-byte pieces per entry
-    float *sv = reinterpret_cast<float *>(lds);                                      // [kWave * 9]
-    float4 *img = reinterpret_cast<float4 *>(lds + sizeof(float) * kWave * 9);       // the wavefront's entries
-    uint32_t *hist = reinterpret_cast<uint32_t *>(lds + sizeof(float) * kWave * 9 + sizeof(float4) * kWave * NP);
+    float4 *img = reinterpret_cast<float4 *>(lds);                                   // the wavefront's entries
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds + sizeof(float4) * kWave * NP);
     const int lane = threadIdx.x;
     const int64_t b0 = group * kWave;
     const int n = (int)((T - b0) < kWave ? (T - b0) : kWave);
@@ -625,38 +601,26 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
     // as needed, between the bounding box and pass A: one more wait in the chain)
 #pragma unroll
     for (int i = 0; i < kWaveHistTiles / kWave; ++i) hist[i * kWave + lane] = 0;
-    // (CR_SETUP_DIRECT: each lane loads and stores its own 36-byte record — every byte of every line
-    // is some lane's — instead of going through an LDS staging buffer: one LDS round trip and a
-    // wait less in a kernel that is a chain of waits)
-    if (!CR_SETUP_DIRECT) stage_in<kWave>(tri_in + b0 * 9, sv, n * 9);
+    // (each lane loads and stores its own 36-byte record — every byte of every line is some lane's —
+    // instead of going through an LDS staging buffer: one LDS round trip and a wait less in a kernel
+    // that is a chain of waits)
     // only the normals' z components are needed (.pyx:202): three strided loads per lane
     float nz0 = 0.0f, nz1 = 0.0f, nz2 = 0.0f;
     float a[9] = {};
     if (lane < n) {
-        if (CR_SETUP_DIRECT) load9(tri_in + (b0 + lane) * 9, a);
+        load9(tri_in + (b0 + lane) * 9, a);
         const float *nn = nrm + (b0 + lane) * 9;
         nz0 = nn[2]; nz1 = nn[5]; nz2 = nn[8];
     }
-    if (!CR_SETUP_DIRECT) wave_lds_sync();
-    CR_SETUP_STAMP(1);      // inputs staged
+    CR_SETUP_STAMP(1);      // inputs requested
     uint2 r = make_uint2(kNoTiles, 0);
     if (lane < n) {
-        float *v = sv + lane * 9;
-        if (!CR_SETUP_DIRECT) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) a[i] = v[i];
-        }
         if (PROJECT) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) project_vertex(P, a + 3 * c);
-            if (CR_SETUP_DIRECT) {
-                float *o = proj_out + (b0 + lane) * 9;
+            float *o = proj_out + (b0 + lane) * 9;
 #pragma unroll
-                for (int i = 0; i < 9; ++i) o[i] = a[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) v[i] = a[i];
-            }
+            for (int i = 0; i < 9; ++i) o[i] = a[i];
         }
         uint32_t bx = 0, by = 0;
         const TriXYZ t{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]};
@@ -668,6 +632,7 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
                 r.x = kNoTiles;
             }
         }
+
         // this triangle's entry, as every tile of its range will get it
         float4 *e = img + lane * NP;
         e[0] = make_float4(a[0], a[1], a[2], a[3]);
@@ -682,7 +647,6 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
     wave_box(X0, X1, Y0, Y1);
     wave_lds_sync();        // projected vertices and entries visible to every lane
     CR_SETUP_STAMP(2);      // projected, ranges known
-    if (PROJECT && !CR_SETUP_DIRECT) stage_out<kWave>(proj_out + b0 * 9, sv, n * 9);
     if (X1 < 0) return;     // nothing to bin (uniform)
     const int bw = X1 - X0 + 1, area = bw * (Y1 - Y0 + 1);
     if (area > kWaveHistTiles) {
@@ -693,36 +657,42 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
     wave_lds_sync();
     CR_SETUP_STAMP(3);      // pass A done
     {
-        constexpr int kRounds = kWaveHistTiles / kWave;
+        // kWaveHistTiles / kWave rounds of 64 tiles at most, kPassB of them in flight together (all
+        // eight at once held 24 registers across the atomics' round trip: with the raster body's
+        // budget of 72 that put k_frame's binning wavefronts 40 registers into scratch; most
+        // wavefronts have one round, few more than two)
+        constexpr int kPassB = 2;
         const float rbw = 1.0f / (float)bw;
-        uint32_t c[kRounds], t[kRounds], base[kRounds];
         const int nr = (area + kWave - 1) / kWave;      // rounds that have tiles at all (uniform; mostly 1)
+#pragma unroll 1
+        for (int k0 = 0; k0 < nr; k0 += kPassB) {
+            uint32_t c[kPassB], t[kPassB], base[kPassB];
 #pragma unroll
-        for (int k = 0; k < kRounds; ++k) {
-            c[k] = 0u; t[k] = 0u;
-            if (k < nr) {
-                const int i = k * kWave + lane;
+            for (int k = 0; k < kPassB; ++k) {
+                const int i = (k0 + k) * kWave + lane;
                 c[k] = i < area ? hist[i] : 0u;
                 const int dy = (int)(((float)i + 0.5f) * rbw);          // exact: i < 2^22
                 t[k] = (uint32_t)((Y0 + dy) * G.ntx + X0 + (i - dy * bw));
             }
-        }
 #pragma unroll
-        for (int k = 0; k < kRounds; ++k)
-            base[k] = c[k] ? atomicAdd(&count[t[k]], c[k]) : 0u;     // all issued before any is used
+            for (int k = 0; k < kPassB; ++k)
+                base[k] = c[k] ? atomicAdd(&count[t[k]], c[k]) : 0u;     // issued together
 #pragma unroll
-        for (int k = 0; k < kRounds; ++k) {
-            if (c[k]) {
-                hist[k * kWave + lane] = base[k];
-                if (base[k] + c[k] > dcap) atomicMax(&hdr[1], base[k] + c[k]);
-                if (hv.ctr && base[k] < kHeavyAt && base[k] + c[k] >= kHeavyAt) register_heavy(hv, t[k]);
-                if (base[k] == 0) first_entry_of(hv, t[k]);
+            for (int k = 0; k < kPassB; ++k) {
+                if (c[k]) {
+                    hist[(k0 + k) * kWave + lane] = base[k];
+                    if (base[k] + c[k] > dcap) atomicMax(&hdr[1], base[k] + c[k]);
+                    if (hv.ctr && base[k] < kHeavyAt && base[k] + c[k] >= kHeavyAt) register_heavy(hv, t[k]);
+                    if (base[k] == 0) first_entry_of(hv, t[k]);
+                }
             }
         }
     }
     wave_lds_sync();
     CR_SETUP_STAMP(4);      // pass B done (global atomics returned)
-    // a lane's own (narrow) range: every LDS cursor first, then the entries
+    // a lane's own (narrow) range, kPassC tiles at a time: their LDS cursors first, then the entries.
+    // (All sixteen at once, with 64-bit addresses, were the register peak of the whole body: 86
+    // VGPRs beside k_raster's 68.)  The slab is at most kDirectBinBytes long: 32-bit byte offsets.
     {
         int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
         if (r.x != kNoTiles) {
@@ -730,20 +700,30 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
         }
         const int wd = tx1 - tx0 + 1, cnt = wd * (ty1 - ty0 + 1);
         if (cnt <= kWideTiles) {
-            uint32_t slot[kWideTiles];
-            int cx = 0, hrow = (ty0 - Y0) * bw + (tx0 - X0);
+            constexpr int kPassC = 4;
+            int cx = 0, hrow = (ty0 - Y0) * bw + (tx0 - X0), trow = ty0 * G.ntx + tx0;
+            const float4 *mine = img + lane * NP;
+            char *const bin_bytes = reinterpret_cast<char *>(bins);
+#pragma unroll 1
+            for (int k0 = 0; k0 < cnt; k0 += kPassC) {
+                uint32_t slot[kPassC], tile[kPassC];
 #pragma unroll
-            for (int k = 0; k < kWideTiles; ++k) {
-                slot[k] = k < cnt ? atomicAdd(&hist[hrow + cx], 1u) : 0u;
-                if (++cx == wd) { cx = 0; hrow += bw; }
-            }
-            cx = 0;
-            int trow = ty0 * G.ntx + tx0;
+                for (int k = 0; k < kPassC; ++k) {
+                    tile[k] = (uint32_t)(trow + cx);
+                    slot[k] = k0 + k < cnt ? atomicAdd(&hist[hrow + cx], 1u) : 0xFFFFFFFFu;
+                    if (++cx == wd) { cx = 0; hrow += bw; trow += G.ntx; }
+                }
+                float4 e[NP];
 #pragma unroll
-            for (int k = 0; k < kWideTiles; ++k) {
-                if (k < cnt && slot[k] < dcap)
-                    put_entry<NP>(bins + ((size_t)(trow + cx) * dcap + slot[k]) * NP, img, lane);
-                if (++cx == wd) { cx = 0; trow += G.ntx; }
+                for (int q = 0; q < NP; ++q) e[q] = mine[q];
+#pragma unroll
+                for (int k = 0; k < kPassC; ++k) {
+                    if (slot[k] < dcap) {
+                        float4 *dst = reinterpret_cast<float4 *>(bin_bytes + (uint32_t)((tile[k] * dcap + slot[k]) * (uint32_t)sizeof(BinEntry)));
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) dst[q] = e[q];
+                    }
+                }
             }
             r.x = kNoTiles;   // done; only wide ranges are left for the cooperative walk
         }
@@ -1047,7 +1027,6 @@ CR_DEV void lds_key_min(unsigned long long *slot, unsigned long long k)
 // every covered tile's critical path.
 CR_DEV uint32_t wave_incl_sum(uint32_t v)
 {
-#if CR_DPP_SCAN
     int x = (int)v;
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
     x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
@@ -1056,15 +1035,6 @@ CR_DEV uint32_t wave_incl_sum(uint32_t v)
     x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
     return (uint32_t)x;
-#else
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-#endif
 }
 
 // One batch of (tile, triangle) work in LDS, struct-of-arrays, slot = thread index.
@@ -1076,13 +1046,24 @@ struct WorkQueue {
     float x1[kThreads], y1[kThreads], z1[kThreads];
     float x2[kThreads], y2[kThreads], z2[kThreads];
     uint32_t tri[kThreads];
-    uint32_t box_xy[kThreads];    // bx0 | by0 << 16  (frame pixel coordinates)
-    uint32_t box_wh[kThreads];    // bw  | bh  << 16  (0 = no work)
-    uint32_t blk_scan[kThreads];  // exclusive prefix of item counts within the wavefront
+    // the record's pixel box clipped to the tile, TILE-LOCAL and packed: x0 | y0 << 6 | w << 12 |
+    // h << 19 (w = 0: no work).  One word instead of two: with the small-record batches' private
+    // arrays below the 32-pixel kernel stays at six workgroups per CU (27 136 bytes of LDS each).
+    uint32_t box[kThreads];
     uint32_t wave_blocks[kThreads / 64];
-    unsigned long long mask[kThreads];  // large-record batches: blocks that survive the cull
-    // 32-pixel tiles count a batch both ways (blocks above, pixels here) and pick the sweep after
-    uint32_t px_scan[kThreads];
+    // a batch is swept one way or the other: the two sweeps' private arrays share their memory
+    union {
+        struct {
+            unsigned long long mask[kThreads];  // large-record batches: blocks that survive the cull
+            uint32_t blk_scan[kThreads];        // exclusive prefix of the records' block counts within the wavefront
+        } big;
+        struct {                            // small-record batches of 32-pixel tiles: what depends on the
+            float l03[kThreads], l13[kThreads], l23[kThreads];   // triangle alone and is not one operation
+            float r1[kThreads], r2[kThreads], r3[kThreads];      // away — the denominators of mu.pyx:11-21 and
+            uint32_t px_scan[kThreads];                          // their refined reciprocals (r1 = 0: none);
+        } pre;                                                   // exclusive prefix of the records' item counts
+    };
+    // 32-pixel tiles count a batch both ways (blocks above, pixels in pre.px_scan) and pick the sweep after
     uint32_t wave_px[kThreads / 64];
 };
 
@@ -1189,6 +1170,18 @@ struct Work {
 
 CR_DEV int box_w(uint32_t wh) { return (int)(wh & 0xFFFF); }
 CR_DEV int box_h(uint32_t wh) { return (int)(wh >> 16); }
+// WorkQueue::box: tile-local packed box <-> (xy, wh) in frame coordinates (xy = x0 | y0 << 16, wh = w | h << 16)
+CR_DEV uint32_t pack_box(uint32_t xy, uint32_t wh, int X0, int Y0)
+{
+    if (wh == 0) return 0u;
+    return (uint32_t)((int)(xy & 0xFFFF) - X0) | ((uint32_t)((int)(xy >> 16) - Y0) << 6) | ((wh & 0x7Fu) << 12) |
+           ((wh >> 16) << 19);
+}
+CR_DEV uint32_t packed_wh(uint32_t b) { return ((b >> 12) & 0x7Fu) | ((b >> 19) << 16); }
+CR_DEV uint32_t packed_xy(uint32_t b, int X0, int Y0)
+{
+    return (uint32_t)(X0 + (int)(b & 0x3Fu)) | ((uint32_t)(Y0 + (int)((b >> 6) & 0x3Fu)) << 16);
+}
 
 CR_DEV int blocks_of(uint32_t box_wh)
 {
@@ -1196,11 +1189,11 @@ CR_DEV int blocks_of(uint32_t box_wh)
 }
 
 template <typename T>
-CR_DEV Work<T> load_work(const WorkQueue &q, int r)
+CR_DEV Work<T> load_work(const WorkQueue &q, int r, int X0, int Y0)
 {
     Work<T> w;
     w.id = q.tri[r];
-    const uint32_t xy = q.box_xy[r], wh = q.box_wh[r];
+    const uint32_t xy = packed_xy(q.box[r], X0, Y0), wh = packed_wh(q.box[r]);
     w.bx0 = xy & 0xFFFF;
     w.by0 = xy >> 16;
     const int bw = box_w(wh), bh = box_h(wh);
@@ -1234,17 +1227,34 @@ CR_DEV int find_record(const uint32_t *scan, const uint32_t *wo, int p, uint32_t
     return lo;
 }
 
+// True if no pixel of the rectangle [xa, xb] x [ya, yb] can hold a fragment of the triangle: one
+// edge is "surely outside" (raster_math.h (1)) at the corner where its numerator is largest — the
+// numerators are monotone in X and in Y (every rounding step is), so every pixel of the rectangle
+// then fails that edge.  A NaN fails the test (keeps the rectangle); exact, never a guess.
+CR_DEV bool rect_surely_missed(const TriSetup &s, int xa, int xb, int ya, int yb)
+{
+    const float fxa = (float)xa, fxb = (float)xb, fya = (float)ya, fyb = (float)yb;
+    auto worst = [&](float l1, float l2, float ya_, float xb_, float rej) {
+        const float fy = (l1 * rej >= 0.0f) ? fyb : fya;
+        const float fx = (l2 * rej >= 0.0f) ? fxa : fxb;
+        return (l1 * (fy - ya_) - l2 * (fx - xb_)) * rej;
+    };
+    return worst(s.l01, s.l02, s.y2, s.x2, s.rej1) < -kRejTiny ||
+           worst(s.l11, s.l12, s.y0, s.x0, s.rej2) < -kRejTiny ||
+           worst(s.l21, s.l22, s.y1, s.x1, s.rej3) < -kRejTiny;
+}
+
 // Coarse pass of a large-record batch: one lane per dense 4x4 block; surviving blocks are
-// recorded in q.mask.
-CR_DEV void coarse_cull(WorkQueue &q, const uint32_t *wo, int total, int tid,
+// recorded in q.big.mask.
+CR_DEV void coarse_cull(WorkQueue &q, const uint32_t *wo, int total, int tid, int X0, int Y0,
                                                       bool keep_all)
 {
     for (int p = tid; p < total; p += kThreads) {
         uint32_t first;
-        const int r = find_record(q.blk_scan, wo, p, first);
+        const int r = find_record(q.big.blk_scan, wo, p, first);
         const TriSetup s = make_setup(TriXYZ{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
                                              q.x2[r], q.y2[r], q.z2[r]}, false);
-        const uint32_t xy = q.box_xy[r], wh = q.box_wh[r];
+        const uint32_t xy = packed_xy(q.box[r], X0, Y0), wh = packed_wh(q.box[r]);
         const int nbx = (int)((wh & 0xFFFF) + 3) >> 2;
         const int b = (int)first;
         const int by = (int)(((float)b + 0.5f) * (1.0f / (float)nbx)), bx = b - by * nbx;
@@ -1260,7 +1270,7 @@ CR_DEV void coarse_cull(WorkQueue &q, const uint32_t *wo, int total, int tid,
         const bool o1 = worst(s.l01, s.l02, s.y2, s.x2, s.rej1) < -kRejTiny;
         const bool o2 = worst(s.l11, s.l12, s.y0, s.x0, s.rej2) < -kRejTiny;
         const bool o3 = worst(s.l21, s.l22, s.y1, s.x1, s.rej3) < -kRejTiny;
-        if (keep_all || !(o1 || o2 || o3)) atomicOr(&q.mask[r], 1ull << b);
+        if (keep_all || !(o1 || o2 || o3)) atomicOr(&q.big.mask[r], 1ull << b);
     }
 }
 
@@ -1288,22 +1298,11 @@ __device__ unsigned long long *g_stamps = nullptr;
 // 28 MB of them per 1024^2 frame push the lists and records the covered tiles are about to read out
 // of it; write-through stores cost the same and leave the L2 alone (T-Rex 1024^2: one frame alone
 // 22.8 -> 21.7 us, a launch that only clears 6.8 -> 6.2 us per frame in flight).
-#ifndef CR_CLEAR_POLICY
-#define CR_CLEAR_POLICY 1      // 0 plain, 1 sc1 (write-through), 2 nt
-#endif
 typedef float cr_v4f __attribute__((ext_vector_type(4)));
 CR_DEV void st4(float *p, const float4 &v)
 {
-#if CR_CLEAR_POLICY == 0
-    *reinterpret_cast<float4 *>(p) = v;
-#else
     const cr_v4f x = {v.x, v.y, v.z, v.w};
-#if CR_CLEAR_POLICY == 1
     asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
-#else
-    asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(x) : "memory");
-#endif
-#endif
 }
 template <int TS>
 CR_DEV void clear_rect(float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
@@ -1496,6 +1495,151 @@ CR_DEV void build_order(const uint32_t *__restrict__ count, int ntx, int nty,
     }
 }
 
+// ---- pixel-owner sweep (32-pixel tiles whose whole list is ONE batch of large records) -------------
+// bunny 4096^2 and T-Rex 8192^2 are a few thousand triangles of thousands of pixels each: a tile
+// holds a handful of records that each cover much of it.  The block sweep above computes every
+// covered pixel's barycentrics twice (once for the depth key in LDS, once more in the resolve) and
+// pays an LDS atomic per fragment.  Here the tile's 1024 pixels are OWNED: thread t holds the four
+// x-neighbours (4 * (t & 7) .. + 3, row t >> 3) with their running minimum key AND the winning
+// fragment's barycentrics in registers; the wavefront (eight tile rows) walks the records in a
+// uniform loop, skipping records whose box misses its rows or whose triangle certainly misses its
+// rectangle (the block cull's corner test, raster_math.h (1), on the band), and the resolve only
+// interpolates: no LDS atomics, no second set of divisions, and a thread's four pixels leave as
+// 16-byte stores (z: one, colour and normal: three each).  Same device functions, same keys, same
+// tie rule as the sweeps above: the planes are bit-identical.
+template <bool CLEAR, typename I>
+CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const float *__restrict__ col, const float *__restrict__ nrm,
+                       const uint32_t *__restrict__ pos_of, const Light &Lt, bool vec,
+                       float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
+                       int32_t *__restrict__ win, int W, int X0, int Y0, int X1, int Y1)
+{
+    const int tid = threadIdx.x;
+    const int Xs = X0 + ((tid & 7) << 2), Y = Y0 + (tid >> 3);
+    const int bandY0 = Y0 + ((tid >> 6) << 3), bandY1 = (bandY0 + 8 < Y1) ? bandY0 + 8 : Y1;   // this wavefront's rows
+    const bool row_in = Y < Y1;
+    const I pix0 = (I)((I)Y * (I)W + (I)Xs);
+    unsigned long long best[4];
+    float w1[4], w2[4], w3[4];          // the winner's barycentrics
+    uint32_t slots = 0;                 // the winner's record slot, one byte per pixel
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        best[j] = make_key(zord(1e6f), KEY_LOW_PRIOR);
+        if (!CLEAR && row_in && Xs + j < X1) best[j] = make_key(zord_prior(*elem(zb, (I)(pix0 + j))), KEY_LOW_PRIOR);
+        w1[j] = w2[j] = w3[j] = 0.0f;
+    }
+    for (int r = 0; r < nrec; ++r) {
+        const uint32_t wh = packed_wh(q.box[r]);
+        if (wh == 0) continue;                                   // (uniform: every lane reads the same word)
+        const uint32_t xy = packed_xy(q.box[r], X0, Y0);
+        const int bx0 = (int)(xy & 0xFFFF), by0 = (int)(xy >> 16);
+        const int bx1 = bx0 + box_w(wh), by1 = by0 + box_h(wh);
+        if (by1 <= bandY0 || by0 >= bandY1) continue;            // the box misses this wavefront's rows
+        TriSetup st;
+        {   // the record's setup: differences anew (one operation each), the rest as its thread left it
+            const float4 p0 = *reinterpret_cast<const float4 *>(pre + 8 * r), p1 = *reinterpret_cast<const float4 *>(pre + 8 * r + 4);
+            st.x0 = q.x0[r]; st.y0 = q.y0[r]; st.z0 = q.z0[r];
+            st.x1 = q.x1[r]; st.y1 = q.y1[r]; st.z1 = q.z1[r];
+            st.x2 = q.x2[r]; st.y2 = q.y2[r]; st.z2 = q.z2[r];
+            st.l01 = st.x1 - st.x2; st.l02 = st.y1 - st.y2;
+            st.l11 = st.x2 - st.x0; st.l12 = st.y2 - st.y0;
+            st.l21 = st.x0 - st.x1; st.l22 = st.y0 - st.y1;
+            st.l03 = p0.x; st.l13 = p0.y; st.l23 = p0.z; st.fast = p0.w != 0.0f;
+            st.r1 = p1.x; st.r2 = p1.y; st.r3 = p1.z;
+            st.rej1 = rej_sign(st.l03); st.rej2 = rej_sign(st.l13); st.rej3 = rej_sign(st.l23);
+        }
+        // the triangle certainly misses (box ∩ band): uniform over the wavefront
+        if (rect_surely_missed(st, bx0, bx1 - 1, by0 > bandY0 ? by0 : bandY0, (by1 < bandY1 ? by1 : bandY1) - 1)) continue;
+        const uint32_t low = 0xFFFFFFFEu - q.tri[r];
+        const bool rows_ok = Y >= by0 && Y < by1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = Xs + j;
+            float n1, n2, n3;
+            numerators(st, x, Y, n1, n2, n3);
+            const bool live = rows_ok && x >= bx0 && x < bx1 && !surely_outside(st, n1, n2, n3);
+            if (__any(live)) {                                   // wavefront-uniform
+                if (live) {
+                    float b1, b2, b3;
+                    quotients(st, n1, n2, n3, true, b1, b2, b3);
+                    if (!(b1 < 0.0f || b2 < 0.0f || b3 < 0.0f)) {          // .pyx:215-216 (NaN passes)
+                        const float z = interp(st.z0, st.z1, st.z2, b1, b2, b3);
+                        if (z == z) {                                      // .pyx:220
+                            const unsigned long long k = make_key(zord(z), low);
+                            if (k < best[j]) {
+                                best[j] = k;
+                                w1[j] = b1; w2[j] = b2; w3[j] = b3;
+                                slots = (slots & ~(0xFFu << (8 * j))) | ((uint32_t)r << (8 * j));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- resolve: interpolate the winners and store (.pyx:219, 226-242)
+    if (!row_in || Xs >= X1) return;
+    float zv[4], cv[12], nv[12];
+    int32_t iv[4];
+    bool have[4];
+    uint32_t prev = 0xFFFFFFFFu;
+    float c[9], n[9], z0 = 0.f, z1 = 0.f, z2 = 0.f;
+    uint32_t id = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        have[j] = (uint32_t)best[j] != KEY_LOW_PRIOR;
+        zv[j] = 1e6f; iv[j] = -1;
+        cv[3 * j] = cv[3 * j + 1] = cv[3 * j + 2] = 0.0f;
+        nv[3 * j] = nv[3 * j + 1] = nv[3 * j + 2] = 0.0f;
+        if (have[j]) {
+            const uint32_t sl = (slots >> (8 * j)) & 0xFFu;
+            if (sl != prev) {            // (a thread's four pixels mostly share their winner)
+                prev = sl;
+                id = q.tri[sl];
+                z0 = q.z0[sl]; z1 = q.z1[sl]; z2 = q.z2[sl];
+                const uint32_t at = pos_of ? pos_of[id] : id;
+                load9(elem(col, (I)((I)at * 9)), c);
+                load9(elem(nrm, (I)((I)at * 9)), n);
+            }
+            const float b1 = w1[j], b2 = w2[j], b3 = w3[j];
+            zv[j] = interp(z0, z1, z2, b1, b2, b3);
+            float c0 = interp(c[0], c[3], c[6], b1, b2, b3);
+            float c1 = interp(c[1], c[4], c[7], b1, b2, b3);
+            float c2 = interp(c[2], c[5], c[8], b1, b2, b3);
+            const float n0 = interp(n[0], n[3], n[6], b1, b2, b3);
+            const float n1 = interp(n[1], n[4], n[7], b1, b2, b3);
+            const float n2 = interp(n[2], n[5], n[8], b1, b2, b3);
+            if (Lt.on) {
+                const float f = guro_factor(Lt, n0, n1, n2);
+                c0 *= f; c1 *= f; c2 *= f;
+            }
+            cv[3 * j] = c0; cv[3 * j + 1] = c1; cv[3 * j + 2] = c2;
+            nv[3 * j] = n0; nv[3 * j + 1] = n1; nv[3 * j + 2] = n2;
+            iv[j] = (int32_t)id;
+        }
+    }
+    float *zp = elem(zb, pix0), *cp = elem(cb, (I)(pix0 * 3)), *np_ = elem(nb, (I)(pix0 * 3));
+    int32_t *wp = win ? reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix0)) : nullptr;
+    const bool all4 = Xs + 4 <= X1 && (CLEAR || (have[0] && have[1] && have[2] && have[3]));
+    if (vec && all4) {
+        *reinterpret_cast<float4 *>(zp) = make_float4(zv[0], zv[1], zv[2], zv[3]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            reinterpret_cast<float4 *>(cp)[k] = make_float4(cv[4 * k], cv[4 * k + 1], cv[4 * k + 2], cv[4 * k + 3]);
+            reinterpret_cast<float4 *>(np_)[k] = make_float4(nv[4 * k], nv[4 * k + 1], nv[4 * k + 2], nv[4 * k + 3]);
+        }
+        if (wp) *reinterpret_cast<int4 *>(wp) = make_int4(iv[0], iv[1], iv[2], iv[3]);
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (Xs + j >= X1 || !(CLEAR || have[j])) continue;
+        zp[j] = zv[j];
+        cp[3 * j] = cv[3 * j]; cp[3 * j + 1] = cv[3 * j + 1]; cp[3 * j + 2] = cv[3 * j + 2];
+        np_[3 * j] = nv[3 * j]; np_[3 * j + 1] = nv[3 * j + 1]; np_[3 * j + 2] = nv[3 * j + 2];
+        if (wp) wp[j] = iv[j];
+    }
+}
+
 // the batch: records array-of-structures on 16-pixel tiles (Rec16), else the WorkQueue
 template <int TS>
 constexpr size_t raster_queue_bytes()
@@ -1684,15 +1828,19 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     if (cur_ok && L.orig_of) cur_id = L.orig_of[cur_id];      // from here on: the caller's index
 
     // depth keys of the tile: the prior buffer value (or the cleared value) per pixel
-    const unsigned long long key_clear = make_key(zord(1e6f), KEY_LOW_PRIOR);
-    for (int p = tid; p < TS * TS; p += kThreads) {
-        unsigned long long k = key_clear;
-        if (!CLEAR) {
-            const int x = X0 + (p % TS), y = Y0 + (p / TS);
-            if (x < X1 && y < Y1) k = make_key(zord_prior(zb[(size_t)y * G.W + x]), KEY_LOW_PRIOR);
+    // (32-pixel tiles: once it is known that the tile is not the pixel owners', see below)
+    auto init_keys = [&]() {
+        const unsigned long long key_clear = make_key(zord(1e6f), KEY_LOW_PRIOR);
+        for (int p = tid; p < TS * TS; p += kThreads) {
+            unsigned long long k = key_clear;
+            if (!CLEAR) {
+                const int x = X0 + (p % TS), y = Y0 + (p / TS);
+                if (x < X1 && y < Y1) k = make_key(zord_prior(zb[(size_t)y * G.W + x]), KEY_LOW_PRIOR);
+            }
+            key[p] = k;
         }
-        key[p] = k;
-    }
+    };
+    if constexpr (TS != 32) init_keys();
     CR_STAMP(1);
 #ifdef CRENDER_STAMPS
     if (g_stamps && tid == 0) {
@@ -1714,6 +1862,13 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             if (xl < xr && yt < yb) {
                 box_xy = (uint32_t)xl | ((uint32_t)yt << 16);
                 box_wh = (uint32_t)(xr - xl) | ((uint32_t)(yb - yt) << 16);
+                // A large triangle's pixel box covers about twice its area: a good part of the
+                // entries of a frame of large triangles (bunny 4096^2: 8 per tile) name tiles the
+                // triangle never touches.  Exact test on (box ∩ tile); not worth its ~80
+                // instructions for a small box.
+                if (TS >= 32 && (xr - xl) * (yb - yt) >= 256 &&
+                    rect_surely_missed(make_setup(cur_t, false), xl, xr - 1, yt, yb - 1))
+                    box_wh = 0;
             }
         }
         const uint32_t key_low = slotted ? ((0xFFFFu - (cur_id & 0xFFFFu)) << 16) | ((((base - beg) / kBatch) & 0xFFu) << 8) | (uint32_t)tid
@@ -1779,12 +1934,10 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             q.x1[tid] = cur_t.x1; q.y1[tid] = cur_t.y1; q.z1[tid] = cur_t.z1;
             q.x2[tid] = cur_t.x2; q.y2[tid] = cur_t.y2; q.z2[tid] = cur_t.z2;
             q.tri[tid] = cur_id;
-            q.box_xy[tid] = box_xy;
-            q.box_wh[tid] = box_wh;
-            q.blk_scan[tid] = incl - my_blocks;
+            q.box[tid] = pack_box(box_xy, box_wh, X0, Y0);
+            if constexpr (!either) q.big.blk_scan[tid] = incl - my_blocks;     // (32-pixel tiles: once the sweep is chosen)
             if (lane == 63) q.wave_blocks[wave] = incl;
             if constexpr (either) {
-                q.px_scan[tid] = incl_px - my_px;
                 if (lane == 63) q.wave_px[wave] = incl_px;
             }
         }
@@ -1792,12 +1945,6 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
 #ifdef CRENDER_STAMPS
         if (base == beg) CR_STAMP(6);
 #endif
-
-        // next batch: issue its loads now, they complete under the sweeps
-        const uint32_t nxt = base + kBatch + tid;
-        cur_ok = tid < kBatch && nxt < end;
-        if (cur_ok) cur_ok = load_record(L, proj, G, nxt, cur_id, cur_t, cur_bx, cur_by);
-        if (cur_ok && L.orig_of) cur_id = L.orig_of[cur_id];
 
         // ---- sweep: the batch's work items, flattened and split evenly -------------------------
         {
@@ -1808,6 +1955,26 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + (TS == 16 ? wave16[w] : q.wave_blocks[w]);
             const int total = (int)wo[kThreads / 64];
             const int nrec = (int)((end - base) < (uint32_t)kBatch ? (end - base) : (uint32_t)kBatch);
+            const uint32_t blk_excl = incl - my_blocks;
+            bool small_by_pixel = false;    // 32-pixel tiles: small records go per pixel too
+            if constexpr (either) small_by_pixel = total < 16 * nrec && !(dbg & 8192);
+            if constexpr (either) {
+                if (small_by_pixel) {
+                    // every record's thread works out, ONCE, what an item of its record would otherwise
+                    // work out again (9 items of two pixels per record on the 10 M small triangles:
+                    // 40 of an item's 175 vector instructions)
+                    const TriSetup mine = make_setup(cur_t, true);
+                    q.pre.l03[tid] = mine.l03; q.pre.l13[tid] = mine.l13; q.pre.l23[tid] = mine.l23;
+                    q.pre.r1[tid] = mine.fast ? mine.r1 : 0.0f; q.pre.r2[tid] = mine.r2; q.pre.r3[tid] = mine.r3;
+                    q.pre.px_scan[tid] = incl_px - my_px;
+                    __syncthreads();
+                }
+            }
+            // next batch: issue its loads now, they complete under the sweeps
+            const uint32_t nxt = base + kBatch + tid;
+            cur_ok = tid < kBatch && nxt < end;
+            if (cur_ok) cur_ok = load_record(L, proj, G, nxt, cur_id, cur_t, cur_bx, cur_by);
+            if (cur_ok && L.orig_of) cur_id = L.orig_of[cur_id];
             // Per-pixel sweep: every pixel of every clipped box is one work item; thread t takes
             // items t, t + 256, ...  All lanes work on a sample that lies in its box (a 4x4 block
             // of a small box is mostly empty: 71 % of T-Rex 1024^2's block lanes were inside their
@@ -1851,15 +2018,26 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                             if (fragment16(R, x + j, y, k) && (j == 0 || px0 + j < bw)) lds_key_min(kp + j, k);
                         }
                     } else {
-                        const uint32_t xy = q.box_xy[r];
-                        const int bw = box_w(q.box_wh[r]);
+                        const uint32_t xy = packed_xy(q.box[r], X0, Y0);
+                        const int bw = box_w(packed_wh(q.box[r]));
                         const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
                                        q.x2[r], q.y2[r], q.z2[r]};
                         const uint32_t id = q.tri[r];
                         // the item's samples share its record search, its twelve LDS reads, the nine
                         // edge constants and the refined reciprocals (raster_math.h (2)): per sample
                         // that was 150 vector instructions, a pair costs 175
-                        const TriSetup st = make_setup(t, kItemPixels32 > 1);
+                        TriSetup st;
+                        {
+                            st.x0 = t.x0; st.y0 = t.y0; st.z0 = t.z0; st.x1 = t.x1; st.y1 = t.y1; st.z1 = t.z1;
+                            st.x2 = t.x2; st.y2 = t.y2; st.z2 = t.z2;
+                            st.l01 = t.x1 - t.x2; st.l02 = t.y1 - t.y2;
+                            st.l11 = t.x2 - t.x0; st.l12 = t.y2 - t.y0;
+                            st.l21 = t.x0 - t.x1; st.l22 = t.y0 - t.y1;
+                            st.l03 = q.pre.l03[r]; st.l13 = q.pre.l13[r]; st.l23 = q.pre.l23[r];
+                            st.r1 = q.pre.r1[r]; st.r2 = q.pre.r2[r]; st.r3 = q.pre.r3[r];
+                            st.fast = st.r1 != 0.0f;
+                            st.rej1 = st.rej2 = st.rej3 = 0.0f;
+                        }
                         const int bwn = (bw + kItemPixels32 - 1) / kItemPixels32;
                         // i / bwn for i < 1024, bwn <= 32: the approximate reciprocal is exact enough
                         const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
@@ -1876,8 +2054,35 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                     }
                 }
             };
-            bool small_by_pixel = false;    // 32-pixel tiles: small records go per pixel too
-            if constexpr (either) small_by_pixel = total < 16 * nrec && !(dbg & 8192);
+            if constexpr (TS == 32) {
+                // the whole list is this one batch of large records: the pixels' owners take it from here
+                if (base == beg && end - beg <= (uint32_t)kBatch && !small_by_pixel && !(dbg & 32768)) {
+                    // what depends on the triangle alone — the three denominators of mu.pyx:11-21 and
+                    // their refined reciprocals (raster_math.h (2)) — once per record, by the record's
+                    // thread, into the (unused) key plane: eight words per record
+                    float *pre = reinterpret_cast<float *>(key);
+                    if (tid < nrec) {
+                        const TriSetup st = make_setup(TriXYZ{q.x0[tid], q.y0[tid], q.z0[tid], q.x1[tid], q.y1[tid], q.z1[tid],
+                                                               q.x2[tid], q.y2[tid], q.z2[tid]}, true);
+                        float4 *o = reinterpret_cast<float4 *>(pre + 8 * tid);
+                        o[0] = make_float4(st.l03, st.l13, st.l23, st.fast ? 1.0f : 0.0f);
+                        o[1] = make_float4(st.r1, st.r2, st.r3, 0.0f);
+                    }
+                    __syncthreads();
+                    if (L.addr32)
+                        owner_tile<CLEAR, uint32_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, L.vec_clear != 0, zb, cb, nb, win,
+                                                    G.W, X0, Y0, X1, Y1);
+                    else
+                        owner_tile<CLEAR, size_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, L.vec_clear != 0, zb, cb, nb, win,
+                                                  G.W, X0, Y0, X1, Y1);
+                    CR_STAMP(3);
+                    return;
+                }
+                if (base == beg) {
+                    init_keys();
+                    __syncthreads();
+                }
+            }
             if constexpr (per_pixel) {
                 sweep_pixels(scan16, wo, total);
             } else if (small_by_pixel) {
@@ -1885,7 +2090,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                 wop[0] = 0;
 #pragma unroll
                 for (int w = 0; w < kThreads / 64; ++w) wop[w + 1] = wop[w] + q.wave_px[w];
-                sweep_pixels(q.px_scan, wop, (int)wop[kThreads / 64]);
+                sweep_pixels(q.pre.px_scan, wop, (int)wop[kThreads / 64]);
             } else if (TS == 64 && ((total < 16 * nrec && !(dbg & 8192)) || (dbg & 128))) {
                 // Small records: each of the 16 lane groups takes one contiguous run of blocks,
                 // so a record is set up by (almost) one group only; tight loop, plain division.
@@ -1894,8 +2099,8 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                 const int pend = (p + chunk < total) ? (p + chunk) : total;
                 if (p < pend) {
                     uint32_t first;
-                    int r = find_record(q.blk_scan, wo, p, first);
-                    Work<TriXYZ> wk = load_work<TriXYZ>(q, r);
+                    int r = find_record(q.big.blk_scan, wo, p, first);
+                    Work<TriXYZ> wk = load_work<TriXYZ>(q, r, X0, Y0);
                     int b = (int)first;
                     int by = (int)(((float)b + 0.5f) * (1.0f / (float)wk.nbx)), bx = b - by * wk.nbx;
                     for (;;) {
@@ -1908,7 +2113,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                             if (++bx == wk.nbx) { bx = 0; ++by; }
                         } else {
                             // p < pend guarantees a later record with blocks
-                            do { wk = load_work<TriXYZ>(q, ++r); } while (wk.nblk == 0);
+                            do { wk = load_work<TriXYZ>(q, ++r, X0, Y0); } while (wk.nblk == 0);
                             b = bx = by = 0;
                         }
                     }
@@ -1924,18 +2129,19 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                 // raster_math.h (1)); the divisions that remain use the hoisted reciprocal (2).
                 const bool allow_rej = !(dbg & 32), allow_fast = !(dbg & 64);
                 if constexpr (TS <= 32) {          // a record has at most 64 blocks: one mask word
-                    q.mask[tid] = 0;
+                    q.big.mask[tid] = 0;
+                    if constexpr (either) q.big.blk_scan[tid] = blk_excl;
                     __syncthreads();
                     // ---- coarse pass.  Exact: each numerator is monotone in X and in Y (every
                     // rounding step is), so its extreme over the block sits on a corner; a block
                     // goes only if all four corners are "surely outside" the SAME edge, which is
                     // then true of every pixel in it (raster_math.h (1)).
-                    coarse_cull(q, wo, total, tid, (dbg & 4096) != 0);
+                    coarse_cull(q, wo, total, tid, X0, Y0, (dbg & 4096) != 0);
                     __syncthreads();
                     // survivors per record -> the same two-level prefix as the block counts
-                    const uint32_t mine = (uint32_t)__popcll(q.mask[tid]);
+                    const uint32_t mine = (uint32_t)__popcll(q.big.mask[tid]);
                     const uint32_t inc = wave_incl_sum(mine);
-                    q.blk_scan[tid] = inc - mine;
+                    q.big.blk_scan[tid] = inc - mine;
                     if (lane == 63) q.wave_blocks[wave] = inc;
                     __syncthreads();
 #pragma unroll
@@ -1948,11 +2154,11 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                     const int pend = (p + chunk < work) ? (p + chunk) : work;
                     if (p < pend) {
                         uint32_t first;
-                        int r = find_record(q.blk_scan, wo, p, first);
-                        Work<TriSetup> wk = load_work<TriSetup>(q, r);
+                        int r = find_record(q.big.blk_scan, wo, p, first);
+                        Work<TriSetup> wk = load_work<TriSetup>(q, r, X0, Y0);
                         float inv_nbx = 1.0f / (float)wk.nbx;
                         // the record's survivor mask with everything before the current block cleared
-                        unsigned long long m = q.mask[r];
+                        unsigned long long m = q.big.mask[r];
                         for (uint32_t i = 0; i < first; ++i) m &= m - 1;
                         for (;;) {
                             const int b = __ffsll((long long)m) - 1;
@@ -1966,8 +2172,8 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                             if (++p >= pend) break;   // (p < pend guarantees another survivor)
                             m &= m - 1;
                             if (m == 0) {
-                                do { m = q.mask[++r]; } while (m == 0);
-                                wk = load_work<TriSetup>(q, r);
+                                do { m = q.big.mask[++r]; } while (m == 0);
+                                wk = load_work<TriSetup>(q, r, X0, Y0);
                                 inv_nbx = 1.0f / (float)wk.nbx;
                             }
                         }
@@ -1979,8 +2185,8 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                     const int pend = ((wave + 1) * wchunk < total) ? ((wave + 1) * wchunk) : total;
                     if (p < pend) {
                         uint32_t first;
-                        int r = find_record(q.blk_scan, wo, p, first);
-                        Work<TriSetup> wk = load_work<TriSetup>(q, r);
+                        int r = find_record(q.big.blk_scan, wo, p, first);
+                        Work<TriSetup> wk = load_work<TriSetup>(q, r, X0, Y0);
                         int b = (int)first;
                         float inv_nbx = 1.0f / (float)wk.nbx;
                         for (;;) {
@@ -2001,7 +2207,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                             if (b >= wk.nblk) {
                                 do {
                                     b -= wk.nblk;
-                                    wk = load_work<TriSetup>(q, ++r);
+                                    wk = load_work<TriSetup>(q, ++r, X0, Y0);
                                 } while (b >= wk.nblk);
                                 inv_nbx = 1.0f / (float)wk.nbx;
                             }
@@ -2075,7 +2281,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
 }
 
 template <int TS, bool CLEAR>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? CR_WPE16 : TS == 32 ? CR_WPE32 : 1)))
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? kWavesPerSimd16 : TS == 32 ? kWavesPerSimd32 : 1)))
 void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
               const float *__restrict__ nrm, TileLists L,
               float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
@@ -2102,20 +2308,25 @@ struct RasterArgs {
 };
 static_assert(kSetupWaveLds <= raster_queue_bytes<16>() && kSetupWaveLds <= raster_queue_bytes<32>(),
               "a binning wavefront works in the raster workgroup's batch queue");
+struct FrameArgs {
+    RasterArgs R;
+    SetupArgs S;
+    int nsetup;
+};
 template <int TS, bool CLEAR>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? CR_WPE16 : TS == 32 ? CR_WPE32 : 1)))
-void k_frame(RasterArgs R, SetupArgs S, int nsetup)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? kWavesPerSimd16 : TS == 32 ? kWavesPerSimd32 : 1)))
+void k_frame(FrameArgs A)
 {
     __shared__ unsigned long long key[TS * TS];
     __shared__ __attribute__((aligned(16))) unsigned char qraw[raster_queue_bytes<TS>()];
-    if ((int)blockIdx.x < nsetup) {
+    if ((int)blockIdx.x < A.nsetup) {
         if (threadIdx.x < kWave)
-            setup_wave_body<TS, true>(S.tri_in, S.nrm, S.proj_out, S.count, S.bins, S.dcap, S.hdr, S.hv, S.T,
-                                      S.P, S.G, (int64_t)blockIdx.x, qraw);
+            setup_wave_body<TS, true>(A.S.tri_in, A.S.nrm, A.S.proj_out, A.S.count, A.S.bins, A.S.dcap, A.S.hdr,
+                                      A.S.hv, A.S.T, A.S.P, A.S.G, (int64_t)blockIdx.x, qraw);
         return;
     }
-    raster_body<TS, CLEAR>(R.proj, R.col, R.nrm, R.L, R.zb, R.cb, R.nb, R.win, R.G, R.dbg,
-                           (int)blockIdx.x - nsetup, key, qraw);
+    raster_body<TS, CLEAR>(A.R.proj, A.R.col, A.R.nrm, A.R.L, A.R.zb, A.R.cb, A.R.nb, A.R.win, A.R.G, A.R.dbg,
+                           (int)blockIdx.x - A.nsetup, key, qraw);
 }
 
 // ---- second implementation: global 64-bit atomics ---------------------------------
@@ -2521,6 +2732,11 @@ struct crender_pipeline {
         unsigned flags = 0;
     } primed[kMaxPipelineDepth];
     uint64_t n = 0;           // frames submitted since the last join
+    // optional HIP events around every frame's launches on its own stream
+    // (crender_pipeline_timing_begin): 2 per frame
+    std::vector<hipEvent_t> events;
+    int timed_frames = 0;
+    bool timing() const { return (size_t)(timed_frames + 1) * 2 <= events.size(); }
     const void *last_tri = nullptr, *last_nrm = nullptr;
     int64_t last_T = -1;
     hipStream_t last_caller = nullptr;
@@ -2734,7 +2950,7 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     tl.grouped_next = ordered ? plan->grouped(hp ^ 1) : nullptr;
     tl.hint_bad = plan->hdr() + 5 + par;
     tl.hint_bad_next = plan->hdr() + 5 + (par ^ 1);
-    tl.addr32 = CR_ADDR32 && (uint64_t)G.H * (uint64_t)G.W * 12ull < (1ull << 32) &&
+    tl.addr32 = (uint64_t)G.H * (uint64_t)G.W * 12ull < (1ull << 32) &&
                 (uint64_t)(plan->last_T > 0 ? plan->last_T : 1) * 36ull < (1ull << 32);
     if (ordered) plan->hint_par = hp ^ 1;
     const uintptr_t any = (uintptr_t)d_z | (uintptr_t)d_color | (uintptr_t)d_normal | (uintptr_t)d_winner;
@@ -2746,12 +2962,11 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
             // this frame's raster pass and another plan's binning pass in one launch (k_frame)
             const int nsetup = (int)((with_setup->T + kWave - 1) / kWave);
             const RasterArgs ra{proj, d_col, d_nrm, tl, d_z, d_color, d_normal, d_winner, G, dbg};
+            const FrameArgs fa{ra, *with_setup, nsetup};
             if (flags & CRENDER_FUSED_CLEAR)
-                hipLaunchKernelGGL((k_frame<TS, true>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, ra,
-                                   *with_setup, nsetup);
+                hipLaunchKernelGGL((k_frame<TS, true>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, fa);
             else
-                hipLaunchKernelGGL((k_frame<TS, false>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, ra,
-                                   *with_setup, nsetup);
+                hipLaunchKernelGGL((k_frame<TS, false>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, fa);
             CR_LAUNCH_CHECK("k_frame");
             plan->awaiting[par ^ 1] = false;
             return CRENDER_OK;
@@ -3081,8 +3296,8 @@ static int crender_render_model_on(crender_plan *plan, const float *d_tri, const
 
 int crender_pipeline_create(crender_pipeline **out, crender_plan *const *plans, int depth)
 {
-    if (!out || !plans || depth < 2 || depth > kMaxPipelineDepth)
-        return fail(CRENDER_EINVAL, "crender_pipeline_create: need 2..8 plans");
+    if (!out || !plans || depth < 1 || depth > kMaxPipelineDepth)
+        return fail(CRENDER_EINVAL, "crender_pipeline_create: need 1..8 plans");
     for (int i = 0; i < depth; ++i)
         for (int j = 0; j <= i; ++j)
             if (!plans[i] || (j < i && plans[i] == plans[j]))
@@ -3116,6 +3331,7 @@ void crender_pipeline_destroy(crender_pipeline *p)
         if (p->s[k]) (void)hipStreamDestroy(p->s[k]);
     }
     if (p->mark) (void)hipEventDestroy(p->mark);
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
     delete p;
 }
 
@@ -3139,6 +3355,18 @@ int crender_pipeline_frame(crender_pipeline *p, const float *d_tri, const float 
         p->synced = true;
     }
     const int k = (int)(p->n % (uint64_t)p->depth);
+    const bool timed = p->timing();
+    if (timed) CR_HIP(hipEventRecord(p->events[(size_t)p->timed_frames * 2], p->s[k]));
+    struct Stamp {      // the closing event, whichever way the frame leaves this function with success
+        crender_pipeline *p; int k; bool on;
+        int close() {
+            if (!on) return CRENDER_OK;
+            on = false;
+            CR_HIP(hipEventRecord(p->events[(size_t)p->timed_frames * 2 + 1], p->s[k]));
+            p->timed_frames++;
+            return CRENDER_OK;
+        }
+    } stamp{p, k, timed};
     if (p->ahead[k] && P16 && T > 0) {
         // One launch per frame: this frame's raster pass together with the binning pass of the
         // slot's NEXT frame — expected to come with the same inputs — into the slot's other plan.
@@ -3166,7 +3394,7 @@ int crender_pipeline_frame(crender_pipeline *p, const float *d_tri, const float 
         std::memcpy(pr.P, P16, sizeof pr.P);
         p->sel[k] ^= 1;
         p->n++;
-        return CRENDER_OK;
+        return stamp.close();
     }
     // plan k and framebuffer set k were last used by frame n - depth, earlier on this same stream
     // (a frame that cannot look ahead — no triangles, projected input — takes the slot's first plan
@@ -3177,6 +3405,40 @@ int crender_pipeline_frame(crender_pipeline *p, const float *d_tri, const float 
                                      d_winner, flags, p->s[k]);
     if (rc != CRENDER_OK) return rc;
     p->n++;
+    return stamp.close();
+}
+
+int crender_pipeline_timing_begin(crender_pipeline *p, int max_frames)
+{
+    if (!p || max_frames < 0) return fail(CRENDER_EINVAL, "crender_pipeline_timing_begin: bad argument");
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    p->events.clear();
+    p->timed_frames = 0;
+    p->events.reserve((size_t)max_frames * 2);
+    for (int i = 0; i < max_frames * 2; ++i) {
+        hipEvent_t e;
+        CR_HIP(hipEventCreate(&e));
+        p->events.push_back(e);
+    }
+    return CRENDER_OK;
+}
+
+int crender_pipeline_timing_end(crender_pipeline *p, int *frames, double *launch_ms_avg)
+{
+    if (!p) return fail(CRENDER_EINVAL, "null pipeline");
+    for (int k = 0; k < p->depth; ++k) CR_HIP(hipStreamSynchronize(p->s[k]));
+    double sum = 0.0;
+    const int n = p->timed_frames;
+    for (int f = 0; f < n; ++f) {
+        float ms = 0.f;
+        CR_HIP(hipEventElapsedTime(&ms, p->events[(size_t)f * 2], p->events[(size_t)f * 2 + 1]));
+        sum += ms;
+    }
+    if (frames) *frames = n;
+    if (launch_ms_avg) *launch_ms_avg = n ? sum / n : 0.0;
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    p->events.clear();
+    p->timed_frames = 0;
     return CRENDER_OK;
 }
 

@@ -119,28 +119,28 @@ def _tri_ptrs(tri, col, nrm):
     return tri.data_ptr(), col.data_ptr(), nrm.data_ptr(), tri.shape[0]
 
 
-def _flags(clear, direct_bins):
-    return (_capi.FUSED_CLEAR if clear else 0) | (0 if direct_bins else _capi.NO_DIRECT_BINS)
+def _flags(clear, direct_bins, extra=0):
+    return (_capi.FUSED_CLEAR if clear else 0) | (0 if direct_bins else _capi.NO_DIRECT_BINS) | int(extra)
 
 
-def raster(plan, proj, col, nrm, fb, clear=False, direct_bins=True):
+def raster(plan, proj, col, nrm, fb, clear=False, direct_bins=True, flags=0):
     """K2 (.pyx:177-244), tile path, on already projected triangles."""
     p, c, n, T = _tri_ptrs(proj, col, nrm)
     with torch.cuda.device(fb.device):
         _capi.check(plan._lib.crender_raster(
             plan.handle, p, c, n, T, fb.z.data_ptr(), fb.color.data_ptr(), fb.normals.data_ptr(),
             fb.winner.data_ptr() if fb.winner is not None else None,
-            _flags(clear, direct_bins), _stream(fb.device)), "crender_raster")
+            _flags(clear, direct_bins, flags), _stream(fb.device)), "crender_raster")
 
 
-def render_model(plan, tri, col, nrm, P, fb, clear=False, direct_bins=True):
+def render_model(plan, tri, col, nrm, P, fb, clear=False, direct_bins=True, flags=0):
     """render_model (.pyx:92-104): K1 fused into the binning pass + K2."""
     p, c, n, T = _tri_ptrs(tri, col, nrm)
     with torch.cuda.device(fb.device):
         _capi.check(plan._lib.crender_render_model(
             plan.handle, p, c, n, T, _capi.f32_16(P), fb.z.data_ptr(), fb.color.data_ptr(),
             fb.normals.data_ptr(), fb.winner.data_ptr() if fb.winner is not None else None,
-            _flags(clear, direct_bins), _stream(fb.device)), "crender_render_model")
+            _flags(clear, direct_bins, flags), _stream(fb.device)), "crender_render_model")
 
 
 def prepare(plan, tri, nrm, P, stream=None, direct_bins=True):

@@ -22,10 +22,13 @@ Behaviour kept from the reference
     (GuroIllumination does, guro_illumination.py:27) and that show every later render, like the
     reference's views of its own buffers (.pyx:246-253): in-place changes are carried to the
     device before the next render, and every array handed out so far is refreshed at the end of
-    each ``render_model``;
+    each ``render_model``.  The arrays are views of PINNED host buffers allocated once per plane;
+    only planes that have actually been handed out cross PCIe (one asynchronous copy each way
+    per render), a filler nobody asked a buffer of copies nothing;
   * the three model arrays are read afresh on every ``render_model`` call, as the reference's
     per-call ``.copy()`` does (.pyx:94-96): an in-place edit of ``model._vertices_by_triangles``
-    is honoured (``cache_inputs=True`` restores the upload cache keyed by array identity);
+    is honoured (``cache_inputs=True`` restores the upload cache keyed by array identity).
+    numpy arrays go up through ONE pinned staging buffer and one asynchronous copy;
   * ``model._colors_by_triangles is None`` raises AttributeError, float64 arrays raise
     ValueError (.pyx:94-96 binds ``float[:, :, :]`` after ``.copy()``);
   * ``n_threads`` is accepted and ignored.
@@ -41,6 +44,19 @@ import numpy as np
 import torch
 
 from .. import _capi, _torch_ext
+
+
+def _check_host_f32(a, name):
+    """numpy view of a [T, 3, 3] float32 host array (any strides), with the reference's errors."""
+    if a is None:
+        raise AttributeError("'NoneType' object has no attribute 'copy'")     # .pyx:94-96
+    arr = np.asarray(a)
+    if arr.dtype != np.float32:
+        kind = "double" if arr.dtype == np.float64 else str(arr.dtype)
+        raise ValueError(f"Buffer dtype mismatch, expected 'float' but got '{kind}'")
+    if arr.ndim != 3 or arr.shape[1] != 3 or arr.shape[2] != 3:
+        raise ValueError(f"{name} must have shape [T, 3, 3], got {tuple(arr.shape)}")
+    return arr
 
 
 def _as_device_f32(a, name, device):
@@ -189,6 +205,17 @@ class _FramePipeline:
     def overflowed(self, filler):
         return self.overflow(filler) is not None
 
+    def timing_begin(self, max_frames):
+        _capi.check(self.lib.crender_pipeline_timing_begin(self.handle, int(max_frames)),
+                    "crender_pipeline_timing_begin")
+
+    def timing_end(self):
+        """-> (frames, average ms between the events around each frame's launches on its stream)."""
+        n, ms = C.c_int(), C.c_double()
+        _capi.check(self.lib.crender_pipeline_timing_end(self.handle, C.byref(n), C.byref(ms)),
+                    "crender_pipeline_timing_end")
+        return n.value, ms.value
+
 
 class AdvancedPixelBufferFiller:
     def __init__(self, h, w, fov=90.0, z_near=0.1, z_far=1000.0, n_threads=1, *,
@@ -233,10 +260,15 @@ class AdvancedPixelBufferFiller:
         self._input_key = None
         self._last_flags = 0
         self._extra_flags = 0 if direct_bins else _capi.NO_DIRECT_BINS
-        self._host = {}                # name -> numpy mirror handed out by a getter
+        self._host = {}                # name -> numpy mirror handed out by a getter (view of _host_pin[name])
+        self._host_pin = {}            # name -> pinned host tensor behind the mirror
         self._host_fresh = False       # mirrors equal the device buffers
         self._host_exposed = False     # a mirror was handed out and may have been edited
+        self._stage = None             # (pinned [3, T, 3, 3], device [3, T, 3, 3]): numpy inputs' way up
+        self._stage_done = None        # event: the staging buffer's last copy has left the host
+        self._sort_cache = None        # (key of caller-owned tensors, sorted inputs, order)
         self._unverified = False       # a frame was launched whose bin lists have not been checked
+        self._redone = False
         # Tile-coherent copy of large models (crender_plan_set_triangle_order): None = from 2^18
         # triangles on, True / False = always / never.  Made once per upload; results do not change.
         self._presort = presort
@@ -258,7 +290,7 @@ class AdvancedPixelBufferFiller:
             except ValueError:
                 queues = 4
             pipeline_depth = 4 if (self.h * self.w <= 1024 * 1024 and queues >= 6) else 3
-        self._pipeline_depth = max(2, min(8, int(pipeline_depth)))
+        self._pipeline_depth = max(1, min(8, int(pipeline_depth)))   # (1: frames one after another on ONE stream of the chain)
         self._pipe = None
         self._checking = False
 
@@ -302,6 +334,9 @@ class AdvancedPixelBufferFiller:
                     "crender_plan_create")
         self._plan = plan
         self._plan_max_T = max_T
+        # a fresh plan has no triangle order and no light, whatever the address the allocator gave
+        # it (a same-sized new after delete usually returns the old one)
+        self._plan_order = self._plan_light = None
         need, cap = C.c_int64(), C.c_int64()
         _capi.check(self._lib.crender_plan_last_bin_usage(plan, self._stream(), C.byref(need),
                                                           C.byref(cap)), "crender_plan_last_bin_usage")
@@ -320,8 +355,8 @@ class AdvancedPixelBufferFiller:
             return
         for name, buf in (("z", self.z_buffer), ("color", self.color_buffer),
                           ("normals", self.normals_buffer)):
-            if name in self._host:
-                buf.copy_(torch.from_numpy(self._host[name]), non_blocking=False)
+            if name in self._host_pin:
+                buf.copy_(self._host_pin[name], non_blocking=True)    # (pinned: one DMA, stream-ordered)
         self._host_exposed = False
 
     def _win_ptr(self):
@@ -336,7 +371,7 @@ class AdvancedPixelBufferFiller:
             # the reference's result (the later call must win equal depths).
             self._check_bins()
         if inputs is not None:
-            self._inputs, self._order = self._tile_coherent(inputs)
+            self._inputs, self._order = self._tile_coherent(inputs, bool(private))
             self._inputs_private = bool(private) or self._order is not None
         tri, col, nrm = self._inputs
         T = tri.shape[0]
@@ -361,18 +396,33 @@ class AdvancedPixelBufferFiller:
         self._host_fresh = False
         self._unverified = True
 
-    def _tile_coherent(self, inputs):
+    def _tile_coherent(self, inputs, private):
         """Large models are kept in HBM in tile-coherent order: sorted, once per upload, by the
         Morton code of the screen tile each triangle's centroid projects to, so that the raster
         kernel's gathers by list entry and by winning triangle read neighbouring records instead
         of 36-byte needles out of a gigabyte (10 M small triangles: 4.9 GB of HBM traffic per frame
         for 1.5 GB of algorithmic bytes before).  The kernels keep speaking the caller's indices
-        (depth ties, winner plane) through the two index arrays returned with the sorted copies."""
+        (depth ties, winner plane) through the two index arrays returned with the sorted copies.
+
+        Who gets sorted: by default (``presort=None``) only arrays this filler OWNS — numpy inputs it
+        uploaded itself — from 2^18 triangles on.  Device tensors handed in by the caller are used in
+        place as they are (``render_frame`` then sees what the caller writes into them between
+        frames, as for small models); ``presort=True`` sorts those too, which makes the resident copy
+        a SNAPSHOT of the tensors at the time of the ``render_model`` / ``render_arrays`` call: the
+        permutation and the sorted copy are cached per (address, shape, torch version counter) of
+        the three tensors, so repeated calls on unchanged tensors cost nothing and a torch in-place
+        write (which bumps the counter) re-sorts at the next call.  Cost of one sort at 10 M
+        triangles: keys + radix sort + three gathers, about 1 GB of traffic, ~2 ms."""
         tri, col, nrm = inputs
         T = tri.shape[0]
-        want = self._presort if self._presort is not None else T >= (1 << 18)
+        want = self._presort if self._presort is not None else (private and T >= (1 << 18))
         if not want or T < 2 or T >= (1 << 31):
             return inputs, None
+        key = None
+        if not private:
+            key = tuple((a.data_ptr(), tuple(a.shape), a._version) for a in inputs)
+            if self._sort_cache is not None and self._sort_cache[0] == key:
+                return self._sort_cache[1], self._sort_cache[2]
         keys = torch.empty(T, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             _capi.check(self._lib.crender_tile_order_keys(tri.data_ptr(), T, self._P, self.w, self.h,
@@ -384,6 +434,7 @@ class AdvancedPixelBufferFiller:
             orig_of = perm.to(torch.int32)
             pos_of = torch.empty_like(orig_of)
             pos_of[perm] = torch.arange(T, dtype=torch.int32, device=self.device)
+        self._sort_cache = None if key is None else (key, sorted_inputs, (orig_of, pos_of))
         return sorted_inputs, (orig_of, pos_of)
 
     def _check_bins(self):
@@ -391,11 +442,13 @@ class AdvancedPixelBufferFiller:
         Re-rendering is exact: the result is a per-pixel minimum over the prior value and
         all fragments, so fragments that already landed change nothing."""
         self._checking = True
+        self._redone = False
         try:
             self._check_bins_locked()
         finally:
             self._checking = False
         self._unverified = False
+        return self._redone              # True: a frame was rendered again (buffers changed since)
 
     def _check_bins_locked(self):
         if self._pipe is not None and self._pipe.n > 0:
@@ -412,6 +465,7 @@ class AdvancedPixelBufferFiller:
                 torch.cuda.synchronize(self.device)
                 self._pipe.close()
                 self._pipe = None
+                self._redone = True
                 self._launch(_capi.FUSED_CLEAR)
             else:
                 self._pipe.n = 0
@@ -428,6 +482,7 @@ class AdvancedPixelBufferFiller:
             else:
                 self._bin_floor = max(self._bin_floor, int(need.value * 1.25) + 1024)
                 self._ensure_plan(self._inputs[0].shape[0], capacity=self._bin_floor)
+            self._redone = True
             self._launch(self._last_flags)
             self._check_bins_locked()
 
@@ -435,17 +490,17 @@ class AdvancedPixelBufferFiller:
     def get_size(self):
         return self.h, self.w
 
-    def render_model(self, model, refresh=False, clear=False):
+    def render_model(self, model, refresh=False, clear=False, refresh_views=True):
         """Project and rasterize ``model`` on top of the current buffers (.pyx:92-104);
-        ``clear=True`` (extension) renders into freshly initialised buffers in the same pass."""
+        ``clear=True`` (extension) renders into freshly initialised buffers in the same pass.
+        ``refresh_views=False`` (extension) leaves the numpy arrays handed out earlier stale until
+        the next getter call — for callers that go on working on the device first (Renderer)."""
         src = (model._vertices_by_triangles, model._colors_by_triangles, model._normals_by_triangles)
         key = tuple((id(a), getattr(a, "shape", None)) for a in src)
+        private = not any(isinstance(a, torch.Tensor) for a in src)
         if refresh or not self.cache_inputs or key != self._input_key:
-            inputs = (_as_device_f32(src[0], "model._vertices_by_triangles", self.device),
-                      _as_device_f32(src[1], "model._colors_by_triangles", self.device),
-                      _as_device_f32(src[2], "model._normals_by_triangles", self.device))
-            if not (inputs[0].shape == inputs[1].shape == inputs[2].shape):
-                raise ValueError("vertex, colour and normal arrays must have the same shape")
+            inputs = self._upload(src, ("model._vertices_by_triangles", "model._colors_by_triangles",
+                                        "model._normals_by_triangles"), composite=not clear)
             self._input_key = key if self.cache_inputs else None
             self._input_refs = src         # keep ids alive while the key is cached
         else:
@@ -454,12 +509,48 @@ class AdvancedPixelBufferFiller:
             self._host_exposed = False
         else:
             self._push_host_edits()
-        self._launch(_capi.FUSED_CLEAR if clear else 0, inputs,    # (a pending overflow check needs the OLD inputs first)
-                     private=not any(isinstance(a, torch.Tensor) for a in src))
-        if self._host:
+        self._launch(_capi.FUSED_CLEAR if clear else 0, inputs, private=private)
+        if self._host and refresh_views:
             # arrays handed out earlier are views of the reference's own buffers there: they show
             # this render too
             self._refresh_mirrors()
+
+    def _upload(self, src, names, composite):
+        """The three model arrays as [T, 3, 3] float32 device tensors.  Device tensors are taken as
+        they are; numpy arrays go through the filler's pinned staging buffer — three host copies
+        into it (any strides), ONE asynchronous host-to-device copy — into device tensors the
+        filler owns and reuses from call to call."""
+        if any(isinstance(a, torch.Tensor) for a in src) or any(a is None for a in src):
+            inputs = tuple(_as_device_f32(a, n, self.device) for a, n in zip(src, names))
+            if not (inputs[0].shape == inputs[1].shape == inputs[2].shape):
+                raise ValueError("vertex, colour and normal arrays must have the same shape")
+            return inputs
+        arrs = [_check_host_f32(a, n) for a, n in zip(src, names)]
+        if not (arrs[0].shape == arrs[1].shape == arrs[2].shape):
+            raise ValueError("vertex, colour and normal arrays must have the same shape")
+        T = arrs[0].shape[0]
+        # The device side of the staging buffer is what the previous frame was rendered from:
+        # frames still in flight on the swap chain's streams must be done with it, and a frame
+        # whose bin lists have not been verified must be (it would be redone from these tensors).
+        self._join_pipe()
+        if self._unverified and composite:
+            self._check_bins()
+        if self._stage is None or self._stage[0].shape[1] != T:
+            with torch.cuda.device(self.device):
+                self._stage = (torch.empty((3, T, 3, 3), dtype=torch.float32, pin_memory=True),
+                               torch.empty((3, T, 3, 3), dtype=torch.float32, device=self.device))
+            self._stage_np = self._stage[0].numpy()
+            self._stage_done = None
+        if self._stage_done is not None:
+            self._stage_done.synchronize()          # the last copy out of the host buffer has been read
+        for k in range(3):
+            np.copyto(self._stage_np[k], arrs[k])
+        pin, dev = self._stage
+        with torch.cuda.device(self.device):
+            dev.copy_(pin, non_blocking=True)
+            self._stage_done = torch.cuda.Event()
+            self._stage_done.record(torch.cuda.current_stream(self.device))
+        return (dev[0], dev[1], dev[2])
 
     # north_star wording; the reference's method is render_model
     render = render_model
@@ -477,8 +568,7 @@ class AdvancedPixelBufferFiller:
     def render_arrays(self, tri, col, nrm, clear=False):
         """``render_model`` on explicit [T,3,3] float32 arrays (numpy or torch, any device).
         ``clear=True`` renders into freshly initialised buffers in the same pass."""
-        inputs = (_as_device_f32(tri, "tri", self.device), _as_device_f32(col, "col", self.device),
-                  _as_device_f32(nrm, "nrm", self.device))
+        inputs = self._upload((tri, col, nrm), ("tri", "col", "nrm"), composite=not clear)
         self._input_key = None
         if clear:
             self._host_exposed = False
@@ -587,18 +677,28 @@ class AdvancedPixelBufferFiller:
         self._check_bins()
         return self.winner_buffer
 
-    def _refresh_mirrors(self):
-        self._check_bins()
-        for n, b in (("z", self.z_buffer), ("color", self.color_buffer),
-                     ("normals", self.normals_buffer)):
-            if n in self._host:
-                self._host[n][...] = b.cpu().numpy()
-        self._host_fresh = True
+    def _refresh_mirrors(self, only=None):
+        """Bring the handed-out arrays up to date with the device buffers: one asynchronous copy per
+        plane into its pinned buffer, issued BEFORE the synchronising bin-list check so that one wait
+        covers both (a frame that has to be redone — rare — is copied again)."""
+        names = [n for n in self._host_pin if only is None or n in only]
+        while True:
+            self._join_pipe()
+            bufs = {"z": self.z_buffer, "color": self.color_buffer, "normals": self.normals_buffer}
+            for n in names:
+                self._host_pin[n].copy_(bufs[n], non_blocking=True)
+            if not self._check_bins():              # synchronises the stream; True = the frame was redone
+                break
+        if only is None:
+            self._host_fresh = True
 
     def _mirror(self, name, buf):
         if not self._host_fresh:
             self._refresh_mirrors()
         if name not in self._host:
-            self._host[name] = buf.cpu().numpy()
+            with torch.cuda.device(self.device):
+                self._host_pin[name] = torch.empty(tuple(buf.shape), dtype=buf.dtype, pin_memory=True)
+            self._host[name] = self._host_pin[name].numpy()
+            self._refresh_mirrors(only=(name,))
         self._host_exposed = True
         return self._host[name]

@@ -6,17 +6,22 @@ import numpy as np
 
 class Renderer:
     def __init__(self, pixel_buffer_filler, illumination, triangle_iterator_type=None,
-                 image_height=512, image_width=512, use_tqdm=True, on_device=False):
+                 image_height=512, image_width=512, use_tqdm=True, on_device=None):
         self.pixel_buffer_filler = pixel_buffer_filler
         self.illumination = illumination
         self.triangle_iterator_type = triangle_iterator_type   # stored, unused (as in Version C)
         self.im_h = image_height
         self.im_w = image_width
         self.use_tqdm = use_tqdm
-        # on_device=True keeps shading on the GPU and returns the colour TENSOR; the default
-        # reproduces the reference's data flow through writable numpy buffers.
+        # on_device=None (default): same call sequence and same return value as the reference — the
+        #   filler's writable numpy colour buffer — but when the filler keeps its buffers on the GPU
+        #   and the illumination has a device form, the shading runs there, so that only the colour
+        #   plane crosses PCIe (the normals are never handed out);
+        # on_device=False: the reference's data flow to the letter, numpy illumination on the
+        #   filler's host views of colour and normals;
+        # on_device=True: shading on the GPU, returns the colour TENSOR (nothing crosses PCIe);
         # on_device="fused": one model per frame — the frame starts from cleared buffers and the
-        # raster kernel shades each pixel as it stores it (no illumination pass at all).
+        #   raster kernel shades each pixel as it stores it (no illumination pass at all).
         self.on_device = on_device
 
     def render(self, model, normalize_model=False, random_colors=True):
@@ -31,9 +36,14 @@ class Renderer:
             self.illumination.fuse_into(filler)
             filler.render_model(model, clear=True)
             return filler.get_color_tensor()
-        filler.render_model(model)
-        if self.on_device and self.illumination.draw_illumination_device(filler):
-            return filler.get_color_tensor()
+        device_form = getattr(self.illumination, "draw_illumination_device", None)
+        if self.on_device is not False and device_form is not None and hasattr(filler, "get_color_tensor"):
+            # (the views handed out so far are refreshed by the getter below, after the shading)
+            filler.render_model(model, refresh_views=False)
+            if device_form(filler):
+                return filler.get_color_tensor() if self.on_device is True else filler.get_color_buffer()
+        else:
+            filler.render_model(model)
         self.illumination.draw_illumination(filler.get_color_buffer(), filler.get_normals_buffer())
         return filler.get_color_buffer()
 

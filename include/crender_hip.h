@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CRENDER_ABI_VERSION 2
+#define CRENDER_ABI_VERSION 3
 #define CRENDER_API __attribute__((visibility("default")))
 
 enum {
@@ -188,7 +188,8 @@ CRENDER_API int crender_draw(crender_plan *plan, const float *d_tri_proj, const 
                  const float *d_nrm, int64_t T, float *d_z, float *d_color, float *d_normal,
                  int32_t *d_winner, unsigned flags, void *stream);
 
-/* A swap chain, ready-made: one call per frame, up to `depth` (2..8) frames overlap on the GPU.
+/* A swap chain, ready-made: one call per frame, up to `depth` (1..8) frames overlap on the GPU
+ * (depth 1: consecutive frames on ONE stream — with look-ahead each of them a single launch).
  * The pipeline owns `depth` streams; frame i runs (bin pass + raster pass) on stream i % depth
  * with plans[i % depth].  FRAMES IN FLIGHT MUST TARGET DIFFERENT FRAMEBUFFER SETS (a swap
  * chain): nothing orders frame i against frames i+1 .. i+depth-1.  Frames i and i + depth share
@@ -232,6 +233,13 @@ CRENDER_API int crender_pipeline_bind(crender_pipeline *pipeline, int slot, cons
                                       const float *P16, float *d_z, float *d_color, float *d_normal,
                                       int32_t *d_winner, unsigned flags);
 CRENDER_API int crender_pipeline_submit(crender_pipeline *pipeline, void *stream);
+/* Measurement aid (no reference counterpart), the swap chain's counterpart of
+ * crender_plan_timing_*: HIP events on the frame's OWN stream right before and right after the
+ * launch(es) of each of the next `max_frames` frames; crender_pipeline_timing_end synchronises
+ * the pipeline's streams and returns the average.  With look-ahead and depth 1 that is the
+ * duration of one k_frame launch running alone — the kernel a pipelined stream of frames runs. */
+CRENDER_API int crender_pipeline_timing_begin(crender_pipeline *pipeline, int max_frames);
+CRENDER_API int crender_pipeline_timing_end(crender_pipeline *pipeline, int *frames, double *launch_ms_avg);
 
 /* Same contract as crender_raster, computed a second, independent way: one wavefront
  * per triangle, 64-bit global atomics on a packed (z, index) key plane, then a

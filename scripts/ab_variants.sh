@@ -12,7 +12,7 @@ FLAGS=$(python -c "from cython3dmodelrenderer_amd import _build; print(' '.join(
 mkdir -p /tmp/abv
 for v in ${VARIANTS:-cur}; do
   name=${v%%:*}; defs=""; [ "$v" != "$name" ] && defs=$(echo "${v#*:}" | tr ',' ' ')
-  if [ -d variants/$name/csrc ]; then src=variants/$name/csrc/crender_hip.hip; defs="-DCRENDER_DEV_KNOBS $defs"; else src=cython3dmodelrenderer_amd/csrc/crender_hip.hip; defs="-DCRENDER_DEV_KNOBS $defs"; fi
+  if [ -d variants/$name/csrc ]; then src=variants/$name/csrc/crender_hip.hip; defs="-DCRENDER_DEV_KNOBS $defs"; else src=cython3dmodelrenderer_amd/csrc/crender_hip.hip; [ -z "${NODEV:-}" ] && defs="-DCRENDER_DEV_KNOBS $defs"; fi
   /opt/rocm/bin/hipcc $FLAGS $defs -o /tmp/abv/$name.so $src 2>/dev/null || echo "BUILD FAILED $name"
 done
 line() { python -c "
@@ -26,11 +26,11 @@ for w in ${WORKLOADS:-trex1024}; do
     for g in ${DBGS:-0}; do
       [ -d variants/$name/csrc ] && [ $g != 0 ] && continue
       export CRENDER_DEBUG=$g
-      for rep in 1 2; do python bench.py --no-cpu-baseline --workload $w --steps $s --warmup 3 2>/dev/null | line; done
+      for rep in 1 2; do python bench.py --no-cpu-baseline --no-api-calls --workload $w --steps $s --warmup 3 2>/dev/null | line; done
       if [ -n "${PROF:-}" ]; then
         out=/tmp/abv/prof_${name}_$g; rm -rf $out
-        (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $REPO/bench.py --workload $w --steps 100 --warmup 3 --no-cpu-baseline --no-pipeline > $out.log 2>&1
-         TMPDIR=/tmp rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d $out/pmc_sq -- python3 $REPO/bench.py --workload $w --steps 50 --warmup 3 --no-cpu-baseline --no-pipeline >> $out.log 2>&1)
+        (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $REPO/bench.py --workload $w --steps 100 --warmup 3 --no-cpu-baseline --no-api-calls --no-pipeline > $out.log 2>&1
+         TMPDIR=/tmp rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d $out/pmc_sq -- python3 $REPO/bench.py --workload $w --steps 50 --warmup 3 --no-cpu-baseline --no-api-calls --no-pipeline >> $out.log 2>&1)
         python scripts/summarize_prof.py $out 2>/dev/null | grep -E "^k_|^## kernel" | sed "s/^/   [$name dbg=$g] /"
       fi
     done

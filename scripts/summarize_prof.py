@@ -18,6 +18,33 @@ def short(name):
     return name[:40]
 
 
+def split_by_overlap(trace_csv, quiet=False):
+    """Per kernel: average duration of the dispatches that overlap no other dispatch of the same
+    kernel (launches one after another on one stream: the duration is the kernel's own) and of those
+    that do (frames in flight together on the swap chain's streams)."""
+    rows = []
+    for row in csv.DictReader(open(trace_csv)):
+        rows.append((short(row["Kernel_Name"]), int(row["Start_Timestamp"]), int(row["End_Timestamp"]),
+                     row.get("Scratch_Size", row.get("Private_Segment_Size", "?"))))
+    out = {}
+    by = defaultdict(list)
+    for k, a, b, sc in rows:
+        by[k].append((a, b, sc))
+    if not quiet:
+        print("## kernel trace split by overlap with other dispatches of the same kernel")
+    for k, lst in by.items():
+        lst.sort()
+        alone, over = [], []
+        for i, (a, b, sc) in enumerate(lst):
+            hit = (i > 0 and max(e for _, e, _ in lst[max(0, i - 8):i]) > a) or (i + 1 < len(lst) and lst[i + 1][0] < b)
+            (over if hit else alone).append(b - a)
+        out[k] = (alone, over, lst[0][2])
+        if not quiet:
+            fmt = lambda v: f"n={len(v):5d} avg_ns={sum(v) / len(v):12.1f}" if v else "n=    0"
+            print(f"{k:18s} alone: {fmt(alone)}   overlapped: {fmt(over)}   scratch={lst[0][2]}")
+    return out
+
+
 def main(d):
     print(f"# {d}")
     for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
@@ -26,6 +53,7 @@ def main(d):
             print(f"{short(row['Name']):18s} calls={row['Calls']:>6s} avg_ns={float(row['AverageNs']):>12.1f} "
                   f"total_ns={row['TotalDurationNs']:>12s} pct={row['Percentage']}")
     for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        split_by_overlap(f)
         regs = {}
         for row in csv.DictReader(open(f)):
             regs[short(row["Kernel_Name"])] = (row.get("VGPR_Count"), row.get("SGPR_Count"),
