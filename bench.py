@@ -216,6 +216,10 @@ def main():
     ap.add_argument("--exchange", default="planes", choices=["planes", "color", "present"],
                     help="strips: what every rank receives — the three planes (28 B/pixel), the colour "
                          "plane (12) or the presented uint8 image (3)")
+    ap.add_argument("--project", default="local", choices=["local", "broadcast"],
+                    help="strips: who runs K1 — every rank for itself (model replicated, nothing on the "
+                         "links) or rank 0, which broadcasts the projected vertices (36 B/triangle to "
+                         "every rank; north_star's wording)")
     ap.add_argument("--chunks", type=int, default=1,
                     help="strips: sub-strips per rank, each exchanged on a second stream while the "
                          "next one is rasterized")
@@ -260,7 +264,7 @@ def main():
     if strips:
         sr = D.StripRenderer(H, W, rank, world, fov=fov, device=device, tile=args.tile,
                              exchange=args.exchange, chunks=args.chunks,
-                             pipeline=not args.no_pipeline)
+                             pipeline=not args.no_pipeline, project=args.project)
         filler = sr.filler
     else:
         sr = None
@@ -429,7 +433,8 @@ def main():
                        "fov": fov, "row_strips": world if strips else 1,
                        "multi_gpu": ("single GPU" if world == 1 else
                                      f"row strips + {'gloo (host-staged)' if args.backend == 'gloo' else 'RCCL'} "
-                                     f"all-gather, exchange = {args.exchange}, {args.chunks} sub-strip(s) per rank"
+                                     f"all-gather, exchange = {args.exchange}, {args.chunks} sub-strip(s) per rank, "
+                                     f"projection = {'rank 0, broadcast of the projected vertices' if args.project == 'broadcast' else 'every rank its own (model replicated)'}"
                                      if strips else "independent full frames per rank, no collective"),
                        "tile": filler.tile or "auto",
                        "frame": "clear + project + rasterize, model resident in HBM",

@@ -63,6 +63,8 @@ SIGNATURES = {
     "crender_model_stats": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "crender_pipeline_set_lookahead": (_i32, [_vp, _vp, _i32]),
     "crender_model_gather": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "crender_model_rotate": (_i32, [_vp, _i64, C.POINTER(C.c_double), _vp]),
+    "crender_model_vertex_normals": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "crender_model_texture_colors": (_i32, [_vp, _i32, _i64, _vp, _i32, _i32, _vp, _vp]),
 }
 

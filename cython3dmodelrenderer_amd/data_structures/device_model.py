@@ -7,12 +7,29 @@ and the transforms that are exactly reproducible there running as HIP kernels:
 
 each in numpy's own operation order (float32 elementwise; float64 where numpy promotes; the mean
 as numpy's row-after-row float32 sum), so the arrays handed to the filler are, bit for bit, what
-the host ``Model`` produces.  ``rotate`` — and with it the vertex-normal computation it triggers —
-runs on the host ``Model`` and re-uploads (its float32 x float64 ``matmul`` and the ``np.dot``
-threshold of the normal de-duplication go through BLAS kernels whose summation order is not a
-property of the reference).
+the host ``Model`` produces.
+
+``rotate`` — the matrix product and the vertex-normal computation it triggers (model.py:175-208,
+238-256: 1.2 s of Python loops for T-Rex on the host) — runs on the device too
+(``crender_model_rotate``, ``crender_model_vertex_normals``), to 1e-5 of the host ``Model`` rather
+than bit for bit: numpy takes ``matmul``, ``np.linalg.norm`` and ``np.dot`` from its BLAS build,
+whose summation order is not a property of the reference, and the de-duplication test
+``dot >= 1`` is discontinuous, so that a 1-ulp difference can change which face normals a vertex
+averages (a handful of T-Rex's 6 909 vertices; counted in the tests).  ``rotate(angles,
+on_host=True)`` takes the host ``Model``'s path (download, numpy, upload) for callers who need the
+host's bits.
 
 The filler takes torch tensors as they are: ``render_model(device_model)`` uploads nothing.
+The transforms rewrite the resident arrays IN PLACE on the current stream: with frames of a swap
+chain still in flight (``render_frame`` on a pipelined filler) call ``filler.join()`` first — the
+chain's streams are not ordered against the caller's between joins — and hand the model to
+``render_model`` / ``render_arrays`` again afterwards, which re-binds the chain's slots (what was
+binned ahead from the old vertices is dropped).
+
+The mean vertex and the max span are worked out when asked for (``get_mean_vertex``,
+``get_max_span``, ``scale(keep_position=True)``), not after every transform: the mean is numpy's
+sequential float32 sum, one lane per component, which a multi-million-vertex model should not pay
+on every ``shift``.
 """
 from __future__ import annotations
 
@@ -65,6 +82,7 @@ class DeviceModel:
         self._vertices_by_triangles = torch.empty((T, 3, 3), dtype=torch.float32, device=self.device)
         self._normals_by_triangles = torch.empty((T, 3, 3), dtype=torch.float32, device=self.device)
         self._stats = torch.zeros(4, dtype=torch.float32, device=self.device)   # mean[3], max span
+        self._csr = None                 # (offsets, occurrences, face normals, taken): made at the first rotate
         self._gather(self._normals, self._triangles_normals, self._normals_by_triangles)
         self._update()
 
@@ -89,18 +107,42 @@ class DeviceModel:
                                                        index.shape[0], self._stream()), "crender_model_gather")
 
     def _update(self):
-        """model.py:153-160 after a change of the vertices: gather, mean vertex, max span."""
+        """model.py:153-160 after a change of the vertices: the gather now; mean vertex and max span
+        when somebody asks (``_ensure_stats``)."""
         self._gather(self._vertices, self._triangles_vertices, self._vertices_by_triangles)
-        with torch.cuda.device(self.device):
-            _capi.check(self._lib.crender_model_stats(self._vertices.data_ptr(), self._vertices.shape[0],
-                                                      self._stats.data_ptr(), self._stats.data_ptr() + 12,
-                                                      self._stream()), "crender_model_stats")
+        self._stats_valid = False
         self._stats_host = None
+
+    def _ensure_stats(self):
+        if not self._stats_valid:
+            with torch.cuda.device(self.device):
+                _capi.check(self._lib.crender_model_stats(self._vertices.data_ptr(), self._vertices.shape[0],
+                                                          self._stats.data_ptr(), self._stats.data_ptr() + 12,
+                                                          self._stream()), "crender_model_stats")
+            self._stats_valid = True
 
     def _fetch_stats(self):
         if self._stats_host is None:
+            self._ensure_stats()
             self._stats_host = self._stats.cpu().numpy()
         return self._stats_host
+
+    def _vertex_face_csr(self):
+        """Per vertex, the faces of its (face, corner) occurrences in ascending order — the order
+        in which the reference's loop meets them (model.py:178-186); made once per upload."""
+        if self._csr is None:
+            faces = self._triangles_vertices.cpu().numpy().astype(np.int64)          # (non-negative already)
+            flat = faces.ravel()
+            order = np.argsort(flat, kind="stable")           # by vertex; (face, corner) order kept
+            occ = (order // 3).astype(np.int32)
+            V = self._vertices.shape[0]
+            offs = np.zeros(V + 1, np.int64)
+            np.cumsum(np.bincount(flat, minlength=V), out=offs[1:])
+            T = faces.shape[0]
+            self._csr = (self._dev(offs, np.int32), self._dev(occ, np.int32),
+                         torch.empty((T, 3), dtype=torch.float32, device=self.device),
+                         torch.empty(max(3 * T, 1), dtype=torch.uint8, device=self.device))
+        return self._csr
 
     # ----------------------------------------------------------- reference API --
     def shift(self, shift):
@@ -116,6 +158,8 @@ class DeviceModel:
 
     def scale(self, scale_coef, keep_position=True):
         coef = np.float32(scale_coef)            # vtx *= coef is a float32 in-place multiply
+        if keep_position:
+            self._ensure_stats()                 # (the mean the reference subtracts: of the vertices as they are)
         with torch.cuda.device(self.device):
             _capi.check(self._lib.crender_model_scale(self._vertices.data_ptr(), self._vertices.shape[0],
                                                       self._stats.data_ptr(), C.c_float(float(coef)),
@@ -123,13 +167,40 @@ class DeviceModel:
                         "crender_model_scale")
         self._update()
 
-    def rotate(self, angles):
-        """Host side (see the module docstring): download, ``Model.rotate``, upload."""
-        m = self._host
-        m._set_geometry(self._vertices.cpu().numpy(), m._triangles_vertices, m._normals,
-                        m._triangles_normals, recalc=False)
-        m.rotate(angles)
-        self._upload()
+    def rotate(self, angles, on_host=False):
+        """Model.rotate (model.py:238-256): rotate about x, then y, then z (degrees) and recompute
+        the vertex normals — on the device (see the module docstring), or with ``on_host=True``
+        through the host ``Model`` (download, numpy, upload) for the host's bits."""
+        assert len(angles) == 3
+        if on_host:
+            m = self._host
+            m._set_geometry(self._vertices.cpu().numpy(), m._triangles_vertices, m._normals,
+                            m._triangles_normals, recalc=False)
+            m.rotate(angles)
+            self._upload()
+            return
+        from .model import _rot2
+        ax, ay, az = angles
+        rx, ry, rz = np.eye(3), np.eye(3), np.eye(3)
+        rx[1:, 1:] = _rot2(ax)
+        ry[::2, ::2] = _rot2(ay)
+        rz[:2, :2] = _rot2(az)
+        rot = np.matmul(np.matmul(rx, ry), rz)             # float64, composed as the reference composes it
+        R9 = (C.c_double * 9)(*[float(v) for v in rot.reshape(9)])     # new = v @ rot.T: row j of rot per output j
+        offs, occ, fn, taken = self._vertex_face_csr()
+        V, T = self._vertices.shape[0], self._triangles_vertices.shape[0]
+        if self._normals.shape[0] != V:
+            self._normals = torch.empty((V, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.crender_model_rotate(self._vertices.data_ptr(), V, R9, self._stream()),
+                        "crender_model_rotate")
+            _capi.check(self._lib.crender_model_vertex_normals(
+                self._vertices.data_ptr(), V, self._triangles_vertices.data_ptr(), T, offs.data_ptr(),
+                occ.data_ptr(), fn.data_ptr(), taken.data_ptr(), self._normals.data_ptr(), self._stream()),
+                "crender_model_vertex_normals")
+        self._triangles_normals = self._triangles_vertices      # (model.py:168: recalculated normals are per vertex)
+        self._gather(self._normals, self._triangles_normals, self._normals_by_triangles)
+        self._update()
 
     def get_mean_vertex(self):
         return self._fetch_stats()[:3].copy()

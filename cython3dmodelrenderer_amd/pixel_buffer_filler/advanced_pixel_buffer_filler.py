@@ -611,6 +611,33 @@ class AdvancedPixelBufferFiller:
         pipe.frame(self)
         self._host_fresh = False
 
+    def render_projected_frame(self, proj):
+        """One frame — clear + bin + rasterize — from ALREADY PROJECTED vertices (K2 alone,
+        ``crender_raster``; .pyx:177-244) with the resident colours and normals: the receiving side
+        of north_star's "projected vertices broadcast" layout (distributed.StripRenderer).  `proj`
+        is a [T, 3, 3] float32 device tensor in the resident model's triangle order."""
+        self._join_pipe()
+        tri, col, nrm = self._inputs
+        if self._order is not None:
+            raise ValueError("render_projected_frame needs the resident model in the caller's order (presort=False)")
+        if tuple(proj.shape) != tuple(tri.shape) or proj.dtype != torch.float32 or not proj.is_contiguous():
+            raise ValueError("proj must be a contiguous float32 tensor shaped like the resident vertices")
+        T = tri.shape[0]
+        self._ensure_plan(T)
+        if self._plan_order != (self._plan.value, id(None)):
+            _capi.check(self._lib.crender_plan_set_triangle_order(self._plan, None, None),
+                        "crender_plan_set_triangle_order")
+            self._plan_order = (self._plan.value, id(None))
+        flags = _capi.FUSED_CLEAR | self._extra_flags
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.crender_raster(self._plan, proj.data_ptr(), col.data_ptr(), nrm.data_ptr(), T,
+                                                 self.z_buffer.data_ptr(), self.color_buffer.data_ptr(),
+                                                 self.normals_buffer.data_ptr(), self._win_ptr(), flags,
+                                                 self._stream()), "crender_raster")
+        self._last_flags = _capi.FUSED_CLEAR       # (a redo after a bin overflow projects the resident
+        self._host_fresh = False                   #  vertices itself: the same pixels)
+        self._unverified = True
+
     def clear(self):
         """Back to the state __cinit__ leaves (.pyx:65-67)."""
         self._join_pipe()

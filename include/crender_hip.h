@@ -289,7 +289,26 @@ CRENDER_API int crender_present_u8(const float *d_color, unsigned char *d_out, i
  *                         (u, v first; uv_cols >= 2), d_texture uint8 [th][tw][3] -> d_out float32
  *                         [n][3]; crender_model_gather with the faces' texture indices then gives
  *                         colors_by_triangles.  (Parsing .obj / .mtl text stays on the host.)
- * rotate and the vertex-normal computation are not offered: see DESIGN.md. */
+ *   crender_model_rotate  Model.rotate (:238-256), the matrix product: every coordinate the
+ *                         three-term float64 dot product of the float32 vertex with a row of R9 (the
+ *                         host composes mat_rot in float64 as the reference does; row-major 3 x 3),
+ *                         rounded to float32, in place.
+ *   crender_model_vertex_normals  Model._compute_normals_by_vertex (:175-208): unit face normals
+ *                         into d_face_normals [T][3], then per vertex the normalised mean of the
+ *                         distinct ones among the faces that name it, visited in face order
+ *                         (d_offsets int32 [V + 1], d_occurrences int32 [3 T]: per vertex the faces of
+ *                         its (face, corner) occurrences, ascending; d_taken: 3 T bytes of scratch).
+ *                         d_faces int32 [T][3] with non-negative indices.
+ * Unlike the rows above these two agree with numpy to 1e-5, not bit for bit: numpy takes
+ * np.linalg.norm / np.dot / matmul from its BLAS build, whose summation order is not the
+ * reference's property (plain left-to-right float32 here); the de-duplication test `dot >= 1`
+ * is discontinuous, so a 1-ulp difference can change which face normals a vertex averages
+ * (counted and bounded in tests/test_hip_parity_gpu.py::test_device_model_rotate_and_normals). */
+CRENDER_API int crender_model_rotate(float *d_vertices, int64_t V, const double *R9, void *stream);
+CRENDER_API int crender_model_vertex_normals(const float *d_vertices, int64_t V, const int32_t *d_faces, int64_t T,
+                                             const int32_t *d_offsets, const int32_t *d_occurrences,
+                                             float *d_face_normals, unsigned char *d_taken, float *d_normals,
+                                             void *stream);
 CRENDER_API int crender_model_shift(float *d_vertices, int64_t V, const double *shift3,
                                     int shift_is_float32, void *stream);
 CRENDER_API int crender_model_scale(float *d_vertices, int64_t V, const float *d_mean3, float coef,

@@ -255,6 +255,69 @@ def test_two_rank_row_strips_gloo(tmp_path):
         assert f"rank {r} ok" in out
 
 
+_RAGGED_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from cython3dmodelrenderer_amd import distributed as D
+from cython3dmodelrenderer_amd import scenes
+from oracle import oracle as O
+world = 3
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=world)
+rank = dist.get_rank()
+tri, col, nrm = scenes.load_fixture("trex_inputs.npz")
+# ragged frames with sub-strips: ranks own different numbers of rows and of NON-EMPTY sub-strips, yet
+# every rank must take part in every sub-strip's collective (the oracle stands in for the GPU filler)
+for H, W, chunks in ((50, 64, 4), (5, 40, 4), (2, 16, 3), (96, 96, 1), (97, 33, 2)):
+    n = D.chunk_count(H, world, chunks)
+    assert n == max(1, min(chunks, D.strip_height(H, world)))
+    f = O.OracleFiller(H, W, fov=45)
+    mine = 0
+    for k in range(n):
+        a, b = D.substrip_rows(H, world, rank, k, chunks)
+        if b > a:
+            f.render_arrays(tri, col, nrm, y0=a, y1=b)
+            mine += b - a
+    y0, y1 = D.strip_rows(H, world, rank)
+    assert mine == y1 - y0
+    bufs = [torch.from_numpy(b) for b in (f.z_buffer, f.color_buffer, f.normals_buffer)]
+    for k in range(n):                       # exactly n collectives per plane on EVERY rank
+        D.all_gather_substrips(bufs, H, rank, world, k, chunks)
+    full = O.OracleFiller(H, W, fov=45)
+    full.render_arrays(tri, col, nrm)
+    for got, want in zip(bufs, (full.z_buffer, full.color_buffer, full.normals_buffer)):
+        assert np.array_equal(got.numpy().view(np.uint32), want.view(np.uint32)), (H, W, chunks)
+# north_star's broadcast-of-projected-vertices variant, host side of it: rank 0 projects, everybody
+# receives the 36 T bytes and rasterizes its strip from them
+H = W = 64
+f = O.OracleFiller(H, W, fov=45)
+proj = torch.from_numpy(O.project(tri, f.proj_mat, W, H) if rank == 0 else np.zeros_like(tri))
+dist.broadcast(proj, src=0)
+assert np.array_equal(proj.numpy().view(np.uint32), O.project(tri, f.proj_mat, W, H).view(np.uint32))
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_three_rank_ragged_substrips_gloo(tmp_path):
+    """Every rank issues the same number of collectives whatever its share of rows (ragged last
+    strip, empty sub-strips, more sub-strips asked for than a strip has rows)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "ragged_worker.py"
+    script.write_text(_RAGGED_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f"rank {r} ok" in out
+
+
 def test_strip_rows_partition():
     from cython3dmodelrenderer_amd.distributed import strip_rows
     for H, n in [(8192, 8), (1024, 8), (1000, 3), (7, 8), (64, 1)]:
