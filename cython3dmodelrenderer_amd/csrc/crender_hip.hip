@@ -1507,6 +1507,7 @@ CR_DEV void build_order(const uint32_t *__restrict__ count, int ntx, int nty,
 // interpolates: no LDS atomics, no second set of divisions, and a thread's four pixels leave as
 // 16-byte stores (z: one, colour and normal: three each).  Same device functions, same keys, same
 // tie rule as the sweeps above: the planes are bit-identical.
+constexpr uint32_t kOwnFast = 1u << 4;     // flags word of a record: bits 0..3 bands, 4 window, 5..10 signs
 template <bool CLEAR, typename I>
 CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const float *__restrict__ col, const float *__restrict__ nrm,
                        const uint32_t *__restrict__ pos_of, const Light &Lt, bool vec,
@@ -1515,7 +1516,6 @@ CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const flo
 {
     const int tid = threadIdx.x;
     const int Xs = X0 + ((tid & 7) << 2), Y = Y0 + (tid >> 3);
-    const int bandY0 = Y0 + ((tid >> 6) << 3), bandY1 = (bandY0 + 8 < Y1) ? bandY0 + 8 : Y1;   // this wavefront's rows
     const bool row_in = Y < Y1;
     const I pix0 = (I)((I)Y * (I)W + (I)Xs);
     unsigned long long best[4];
@@ -1527,36 +1527,42 @@ CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const flo
         if (!CLEAR && row_in && Xs + j < X1) best[j] = make_key(zord_prior(*elem(zb, (I)(pix0 + j))), KEY_LOW_PRIOR);
         w1[j] = w2[j] = w3[j] = 0.0f;
     }
+    const uint32_t my_band = 1u << (tid >> 6);
     for (int r = 0; r < nrec; ++r) {
+        const float4 p0 = *reinterpret_cast<const float4 *>(pre + 8 * r);
+        const uint32_t flags = __float_as_uint(p0.w);
+        // the triangle cannot touch this wavefront's rows (no work, box or triangle elsewhere): uniform
+        if (!(flags & my_band)) continue;
         const uint32_t wh = packed_wh(q.box[r]);
-        if (wh == 0) continue;                                   // (uniform: every lane reads the same word)
         const uint32_t xy = packed_xy(q.box[r], X0, Y0);
         const int bx0 = (int)(xy & 0xFFFF), by0 = (int)(xy >> 16);
         const int bx1 = bx0 + box_w(wh), by1 = by0 + box_h(wh);
-        if (by1 <= bandY0 || by0 >= bandY1) continue;            // the box misses this wavefront's rows
         TriSetup st;
         {   // the record's setup: differences anew (one operation each), the rest as its thread left it
-            const float4 p0 = *reinterpret_cast<const float4 *>(pre + 8 * r), p1 = *reinterpret_cast<const float4 *>(pre + 8 * r + 4);
+            const float4 p1 = *reinterpret_cast<const float4 *>(pre + 8 * r + 4);
             st.x0 = q.x0[r]; st.y0 = q.y0[r]; st.z0 = q.z0[r];
             st.x1 = q.x1[r]; st.y1 = q.y1[r]; st.z1 = q.z1[r];
             st.x2 = q.x2[r]; st.y2 = q.y2[r]; st.z2 = q.z2[r];
             st.l01 = st.x1 - st.x2; st.l02 = st.y1 - st.y2;
             st.l11 = st.x2 - st.x0; st.l12 = st.y2 - st.y0;
             st.l21 = st.x0 - st.x1; st.l22 = st.y0 - st.y1;
-            st.l03 = p0.x; st.l13 = p0.y; st.l23 = p0.z; st.fast = p0.w != 0.0f;
+            st.l03 = p0.x; st.l13 = p0.y; st.l23 = p0.z; st.fast = (flags & kOwnFast) != 0;
             st.r1 = p1.x; st.r2 = p1.y; st.r3 = p1.z;
-            st.rej1 = rej_sign(st.l03); st.rej2 = rej_sign(st.l13); st.rej3 = rej_sign(st.l23);
+            auto sign_of = [](uint32_t two_bits) { return two_bits == 1u ? 1.0f : two_bits == 2u ? -1.0f : 0.0f; };
+            st.rej1 = sign_of((flags >> 5) & 3u); st.rej2 = sign_of((flags >> 7) & 3u); st.rej3 = sign_of((flags >> 9) & 3u);
         }
-        // the triangle certainly misses (box ∩ band): uniform over the wavefront
-        if (rect_surely_missed(st, bx0, bx1 - 1, by0 > bandY0 ? by0 : bandY0, (by1 < bandY1 ? by1 : bandY1) - 1)) continue;
         const uint32_t low = 0xFFFFFFFEu - q.tri[r];
         const bool rows_ok = Y >= by0 && Y < by1;
+        // numerators() with the row's share of each edge worked out once for the four x-neighbours
+        // (the same operations in the same order: mu.pyx:34 before the division)
+        const float fy = (float)Y;
+        const float ry1 = st.l01 * (fy - st.y2), ry2 = st.l11 * (fy - st.y0), ry3 = st.l21 * (fy - st.y1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int x = Xs + j;
-            float n1, n2, n3;
-            numerators(st, x, Y, n1, n2, n3);
-            const bool live = rows_ok && x >= bx0 && x < bx1 && !surely_outside(st, n1, n2, n3);
+            const float fx = (float)x;
+            const float n1 = ry1 - st.l02 * (fx - st.x2), n2 = ry2 - st.l12 * (fx - st.x0), n3 = ry3 - st.l22 * (fx - st.x1);
+            const bool live = rows_ok && (unsigned)(x - bx0) < (unsigned)(bx1 - bx0) && !surely_outside(st, n1, n2, n3);
             if (__any(live)) {                                   // wavefront-uniform
                 if (live) {
                     float b1, b2, b3;
@@ -2060,12 +2066,33 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                     // what depends on the triangle alone — the three denominators of mu.pyx:11-21 and
                     // their refined reciprocals (raster_math.h (2)) — once per record, by the record's
                     // thread, into the (unused) key plane: eight words per record
+                    // — and which of the four wavefronts' bands of eight rows the triangle can touch at all
+                    // (the exact rectangle test on box ∩ band, once per record instead of once per
+                    // record and wavefront), with the signs of the denominators and the window flag
+                    // in one word: a wavefront passes over a record that is not its business with
+                    // one LDS read
                     float *pre = reinterpret_cast<float *>(key);
                     if (tid < nrec) {
                         const TriSetup st = make_setup(TriXYZ{q.x0[tid], q.y0[tid], q.z0[tid], q.x1[tid], q.y1[tid], q.z1[tid],
                                                                q.x2[tid], q.y2[tid], q.z2[tid]}, true);
+                        const uint32_t bwh = packed_wh(q.box[tid]), bxy = packed_xy(q.box[tid], X0, Y0);
+                        uint32_t flags = st.fast ? kOwnFast : 0u;
+                        flags |= (uint32_t)(st.rej1 > 0.0f ? 1 : st.rej1 < 0.0f ? 2 : 0) << 5;
+                        flags |= (uint32_t)(st.rej2 > 0.0f ? 1 : st.rej2 < 0.0f ? 2 : 0) << 7;
+                        flags |= (uint32_t)(st.rej3 > 0.0f ? 1 : st.rej3 < 0.0f ? 2 : 0) << 9;
+                        if (bwh != 0) {
+                            const int bx0 = (int)(bxy & 0xFFFF), by0 = (int)(bxy >> 16);
+                            const int bx1 = bx0 + box_w(bwh), by1 = by0 + box_h(bwh);
+#pragma unroll
+                            for (int band = 0; band < 4; ++band) {
+                                const int ya = Y0 + 8 * band, yb = (ya + 8 < Y1) ? ya + 8 : Y1;
+                                if (by1 > ya && by0 < yb &&
+                                    !rect_surely_missed(st, bx0, bx1 - 1, by0 > ya ? by0 : ya, (by1 < yb ? by1 : yb) - 1))
+                                    flags |= 1u << band;
+                            }
+                        }
                         float4 *o = reinterpret_cast<float4 *>(pre + 8 * tid);
-                        o[0] = make_float4(st.l03, st.l13, st.l23, st.fast ? 1.0f : 0.0f);
+                        o[0] = make_float4(st.l03, st.l13, st.l23, __uint_as_float(flags));
                         o[1] = make_float4(st.r1, st.r2, st.r3, 0.0f);
                     }
                     __syncthreads();

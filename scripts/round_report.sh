@@ -1,8 +1,38 @@
 #!/bin/bash
 # Runs on the GPU box: the full evidence set of a round -> gpurun_out/report/
 # (copy what is to be judged into profiles/rNN/ afterwards: gpurun_out/ is scratch)
+#   PART=a  smoke, pytest -m gpu, the bench lines
+#   PART=b  rocprofv3: kernel trace + PMC passes, single-stream (k_raster) and pipelined (k_frame)
+#   PART=all (default) both
 cd ${GRAFT_REPO_ROOT:-.}
-OUT=gpurun_out/report; rm -rf $OUT; mkdir -p $OUT
+PART=${PART:-all}
+OUT=gpurun_out/report; mkdir -p $OUT
+# (the profiles first: bench.py reads profiles/kernel_avg.json and profiles/traffic.json of THIS run)
+if [ $PART = b ] || [ $PART = all ]; then
+for w in trex1024 bunny4096 trex8192 synth10m; do
+  rm -rf gpurun_out/prof_$w
+  s=20; [ $w = trex1024 ] && s=100; [ $w = synth10m ] && s=5
+  scripts/profile_gpu.sh $w $s > $OUT/profile_$w.log 2>&1
+  python scripts/summarize_prof.py gpurun_out/prof_$w | grep -v "at::native\|rocclr\|^void" > $OUT/rocprof_$w.txt
+  cp gpurun_out/prof_$w/trace/*/*kernel_stats.csv $OUT/${w}_kernel_stats.csv 2>/dev/null
+done
+# the pipelined run — the driver's own command shape — for the workloads whose frames are k_frame launches
+for w in trex1024 bunny4096 trex8192; do
+  rm -rf gpurun_out/prof_${w}_pipelined
+  s=20; [ $w = trex1024 ] && s=200
+  MODE=pipelined scripts/profile_gpu.sh $w $s > $OUT/profile_${w}_pipelined.log 2>&1
+  python scripts/summarize_prof.py gpurun_out/prof_${w}_pipelined | grep -v "at::native\|rocclr\|^void" > $OUT/rocprof_${w}_pipelined.txt
+  cp gpurun_out/prof_${w}_pipelined/trace/*/*kernel_stats.csv $OUT/${w}_pipelined_kernel_stats.csv 2>/dev/null
+done
+python scripts/make_kernel_avg_json.py gpurun_out > $OUT/kernel_avg.log 2>&1
+cp profiles/kernel_avg.json $OUT/kernel_avg.json
+python scripts/make_traffic_json.py $OUT > $OUT/traffic.log 2>&1
+cp profiles/traffic.json $OUT/traffic.json
+# who overlaps whom on 10 M triangles (three frames of the swap chain march in step)
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d $OLDPWD/gpurun_out/tl_synth -- python3 $OLDPWD/bench.py --workload synth10m --steps 6 --warmup 2 --no-cpu-baseline --no-api-calls > $OLDPWD/$OUT/tl_synth.log 2>&1)
+python scripts/timeline.py gpurun_out/tl_synth 400 2>/dev/null | sed -n 1,60p > $OUT/timeline_synth10m.txt
+fi
+if [ $PART = a ] || [ $PART = all ]; then
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
 timeout -k 10 1100 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu.log
 python bench.py > $OUT/bench_trex1024.json 2> $OUT/bench_trex1024.err; echo "bench rc=$?"
@@ -11,19 +41,5 @@ python bench.py --workload bunny4096 --steps 50 --warmup 5 > $OUT/bench_bunny409
 python bench.py --workload trex8192 --steps 30 --warmup 3 > $OUT/bench_trex8192.json 2>/dev/null
 python bench.py --workload synth10m --steps 10 --warmup 2 > $OUT/bench_synth10m.json 2>/dev/null
 python bench.py --workload cube256 --steps 200 > $OUT/bench_cube256.json 2>/dev/null
-WL="trex1024 cube256" scripts/ab_lookahead.sh > $OUT/lookahead.txt 2>&1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w scripts/ubench/clear_shapes.hip -o /tmp/clear_shapes && /tmp/clear_shapes > $OUT/clear_shapes.txt 2>&1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w scripts/ubench/frame_shape.hip -o /tmp/frame_shape && /tmp/frame_shape > $OUT/frame_shape.txt 2>&1
-python scripts/stamps_overlap.py trex1024 > $OUT/stamps_overlap_trex1024.txt 2>&1
-python scripts/hostcost.py > $OUT/hostcost.txt 2>/dev/null
-python scripts/k20_host.py > $OUT/k20_host.txt 2>/dev/null
-for w in trex1024 bunny4096 trex8192 synth10m; do
-  rm -rf gpurun_out/prof_$w
-  s=20; [ $w = trex1024 ] && s=100; [ $w = synth10m ] && s=5
-  scripts/profile_gpu.sh $w $s > $OUT/profile_$w.log 2>&1
-  python scripts/summarize_prof.py gpurun_out/prof_$w | grep -v "at::native\|rocclr\|^void" > $OUT/rocprof_$w.txt
-  cp gpurun_out/prof_$w/trace/*/*kernel_stats.csv $OUT/${w}_kernel_stats.csv 2>/dev/null
-done
-STAMPS_DEFS="-DCRENDER_DEV_KNOBS" python scripts/stamps.py trex1024 > $OUT/stamps_raster_trex1024.txt 2>&1
-python scripts/stamps_setup.py > $OUT/stamps_setup_trex1024.txt 2>&1
+fi
 ls $OUT
