@@ -2451,7 +2451,7 @@ __global__ __launch_bounds__(kThreads) void k_guro(float *__restrict__ cb, const
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < npix; i += stride) {
         const size_t pix = first_pix + i;
         const float n0 = nb[pix * 3], n1 = nb[pix * 3 + 1], n2 = nb[pix * 3 + 2];
-        const float s = (n0 * l0 + n1 * l1) + n2 * l2;
+        const float s = ((0.0f + n0 * l0) + n1 * l1) + n2 * l2;     // (the reduction starts from +0: see guro_factor)
         const float m = sqrtf((n0 * n0 + n1 * n1) + n2 * n2);
         float c = s / (m + 1e-6f);
         c = c < 0.0f ? 0.0f : c;  // np.clip keeps a NaN a NaN
@@ -2519,14 +2519,26 @@ __global__ __launch_bounds__(kThreads) void k_model_scale(float *__restrict__ v,
 }
 
 // vertices.mean(axis=0): numpy adds the rows one after another into a float32 accumulator per
-// component (no pairwise summation along a strided axis) and divides by the intp count in
-// float64, stored as float32.  One lane per component, sequential.
+// component — the first row is the start value, there is no pairwise summation along a strided
+// axis — and divides by the intp count in float64, stored as float32.  One lane per component; the
+// chain of additions is inherently serial (4 ns each), the LOADS are not: 32 rows are requested
+// together before their 32 additions (one dependent load per row was 0.3 us per vertex: seconds
+// for a model of millions of vertices).
 __global__ void k_model_mean(const float *__restrict__ v, int64_t V, float *__restrict__ mean3)
 {
     const int c = threadIdx.x;
     if (c >= 3) return;
-    float acc = 0.0f;
-    for (int64_t i = 0; i < V; ++i) acc = acc + v[i * 3 + c];
+    constexpr int kAhead = 32;
+    float acc = v[c];
+    int64_t i = 1;
+    for (; i + kAhead <= V; i += kAhead) {
+        float x[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) x[k] = v[(i + k) * 3 + c];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) acc = acc + x[k];
+    }
+    for (; i < V; ++i) acc = acc + v[i * 3 + c];
     mean3[c] = (float)((double)acc / (double)V);
 }
 

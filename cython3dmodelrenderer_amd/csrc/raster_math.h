@@ -303,7 +303,7 @@ CR_DEV TriXYZ load_tri(const float *__restrict__ p)
 }
 
 // f1 fused into the store (CRENDER_FUSED_GURO): guro_illumination.py:20-27 on one pixel, in numpy's
-// float32 operation order — s = (n0*l0 + n1*l1) + n2*l2, m = sqrt((n0*n0 + n1*n1) + n2*n2),
+// float32 operation order — s = ((0 + n0*l0) + n1*l1) + n2*l2, m = sqrt((n0*n0 + n1*n1) + n2*n2),
 // f = clip(s / (m + 1e-6), 0, 1) (a NaN stays a NaN), colour *= f.  The normal is stored as it is.
 struct Light {
     float l0, l1, l2;
@@ -311,10 +311,12 @@ struct Light {
 };
 CR_DEV float guro_factor(const Light &L, float n0, float n1, float n2)
 {
-    const float s = (n0 * L.l0 + n1 * L.l1) + n2 * L.l2;
+    // (numpy's add.reduce over a short axis starts from +0: the three -0 products of a zero normal
+    // under a light along -z sum to +0, not -0 — the sign of the background's shaded colour)
+    const float s = ((0.0f + n0 * L.l0) + n1 * L.l1) + n2 * L.l2;
     const float m = sqrtf((n0 * n0 + n1 * n1) + n2 * n2);
     float f = s / (m + 1e-6f);
-    f = f < 0.0f ? 0.0f : f;
+    f = f < 0.0f ? 0.0f : f;        // (np.clip keeps a NaN, and a -0)
     f = f > 1.0f ? 1.0f : f;
     return f;
 }

@@ -305,3 +305,28 @@ ORACLE_API void oracle_clear(float *zbuf, float *cbuf, float *nbuf, int H, int W
         nbuf[3 * i] = nbuf[3 * i + 1] = nbuf[3 * i + 2] = 0.0f;
     }
 }
+
+/* ---- next row f1: GuroIllumination.draw_illumination, guro_illumination.py:20-27 -----------
+ * The reference's four numpy statements on float32 buffers, one pixel at a time:
+ *   scalar_product = np.sum(n * light, axis=-1)        -> ((0 + n0*l0) + n1*l1) + n2*l2   (numpy's
+ *   norm = np.linalg.norm(n, axis=-1)                  -> sqrt((n0*n0 + n1*n1) + n2*n2)  3-element
+ *   shadow = clip(scalar_product / (norm + 1e-6), 0, 1)                            add.reduce order,
+ *   colour *= shadow                                                               pinned against numpy in
+ * tests/test_oracle_cpu.py::test_oracle_guro_matches_numpy_statements). */
+ORACLE_API void oracle_guro(float *color, const float *normal, const float *light3, int64_t npix)
+{
+    const float l0 = light3[0], l1 = light3[1], l2 = light3[2];
+    for (int64_t i = 0; i < npix; ++i) {
+        const float n0 = normal[3 * i], n1 = normal[3 * i + 1], n2 = normal[3 * i + 2];
+        /* numpy's add.reduce over a short axis starts from +0: three -0 products (a zero normal
+         * under a light along -z) sum to +0, not -0 */
+        const float s = ((0.0f + n0 * l0) + n1 * l1) + n2 * l2;
+        const float m = sqrtf((n0 * n0 + n1 * n1) + n2 * n2);
+        float f = s / (m + 1e-6f);
+        f = f < 0.0f ? 0.0f : f;        /* np.clip keeps a NaN (and a -0) */
+        f = f > 1.0f ? 1.0f : f;
+        color[3 * i] *= f;
+        color[3 * i + 1] *= f;
+        color[3 * i + 2] *= f;
+    }
+}

@@ -69,6 +69,8 @@ def lib():
     L.oracle_render_model.restype = None
     L.oracle_clear.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int]
     L.oracle_clear.restype = None
+    L.oracle_guro.argtypes = [_f32p, _f32p, _f32p, C.c_int64]
+    L.oracle_guro.restype = None
     _lib = L
     return L
 
@@ -100,6 +102,22 @@ def bar(tri9, x, y):
     out = np.zeros(3, np.float32)
     lib().oracle_bar(_c(tri9).reshape(9), int(x), int(y), out)
     return out
+
+
+def guro_light(light_direction):
+    """GuroIllumination.__init__ (guro_illumination.py:15-18): the light vector flipped and
+    normalised, float32."""
+    flipped = -np.asarray(light_direction, dtype="float32")
+    return (flipped / np.linalg.norm(flipped)).astype(np.float32)
+
+
+def guro(color_buffer, normals_buffer, light_direction):
+    """GuroIllumination(light_direction).draw_illumination(color_buffer, normals_buffer)
+    (guro_illumination.py:20-27), in place, by the C restatement oracle_guro."""
+    assert color_buffer.dtype == np.float32 and color_buffer.flags.c_contiguous
+    lib().oracle_guro(color_buffer.reshape(-1), _c(normals_buffer).reshape(-1), guro_light(light_direction),
+                      color_buffer.size // 3)
+    return color_buffer
 
 
 class OracleFiller:

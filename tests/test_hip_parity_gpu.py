@@ -827,15 +827,21 @@ def test_pipeline_c_abi_lookahead(oracle, hip, H, W, flags_extra):
         lib.crender_pipeline_destroy(pipe)
 
 
-def test_renderer_with_illumination(oracle):
+@pytest.mark.parametrize("direction", [[0.3, -0.2, 1], [0, 0, 1]])
+def test_renderer_with_illumination(oracle, direction):
+    """Renderer.render in its four forms against the oracle's render + the oracle's own C
+    restatement of guro_illumination.py:20-27 (``oracle.guro``, pinned against numpy's evaluation of
+    the reference's statements on the CPU).  Light [0, 0, 1] is the signed-zero case: every product
+    of a background pixel's zero normal with the flipped light is -0 and numpy's reduction, which
+    starts from +0, yields +0."""
     from cython3dmodelrenderer_amd import Renderer
     from cython3dmodelrenderer_amd.illumination import GuroIllumination
     from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
     tri, col, nrm = scene("trex_inputs.npz")
-    light = GuroIllumination([0.3, -0.2, 1])
+    light = GuroIllumination(direction)
     f = oracle.OracleFiller(256, 256, fov=45)
     f.render_arrays(tri, col, nrm)
-    light.draw_illumination(f.color_buffer, f.normals_buffer)
+    oracle.guro(f.color_buffer, f.normals_buffer, direction)
     host = Renderer(AdvancedPixelBufferFiller(256, 256, fov=45), light, None, 256, 256, on_device=False)
     img = host.render(_M(tri, col, nrm))
     assert_bit_equal(img, f.color_buffer, "Renderer.render (numpy illumination)")
@@ -849,16 +855,19 @@ def test_renderer_with_illumination(oracle):
     # a second render composites on the shaded buffer, as in the reference (reset_buffers is a no-op)
     cube = scene("cube_inputs.npz")
     f.render_arrays(*cube)
-    light.draw_illumination(f.color_buffer, f.normals_buffer)
+    oracle.guro(f.color_buffer, f.normals_buffer, direction)
     img_b = auto.render(_M(*cube))
     assert img_b is img_a
     assert_bit_equal(img_b, f.color_buffer, "Renderer.render twice (composite on the shaded buffer)")
     f = oracle.OracleFiller(256, 256, fov=45)
     f.render_arrays(tri, col, nrm)
-    light.draw_illumination(f.color_buffer, f.normals_buffer)
+    oracle.guro(f.color_buffer, f.normals_buffer, direction)
     dev = Renderer(AdvancedPixelBufferFiller(256, 256, fov=45), light, None, 256, 256, on_device=True)
     img_d = dev.render(_M(tri, col, nrm)).cpu().numpy()
     assert_bit_equal(img_d, f.color_buffer, "Renderer.render (HIP illumination)")
+    fused = Renderer(AdvancedPixelBufferFiller(256, 256, fov=45), light, None, 256, 256, on_device="fused")
+    img_f = fused.render(_M(tri, col, nrm)).cpu().numpy()
+    assert_bit_equal(img_f, f.color_buffer, "Renderer.render (illumination fused into the raster kernel)")
 
 
 @pytest.mark.parametrize("res,tile", [(256, 0), (300, 32), (192, 64), (1024, 0)])
@@ -874,7 +883,7 @@ def test_fused_guro_equals_the_separate_pass(oracle, hip, res, tile):
     light = GuroIllumination([0.3, -0.2, 1])
     f = oracle.OracleFiller(res, res, fov=45)
     f.render_arrays(tri, col, nrm)
-    light.draw_illumination(f.color_buffer, f.normals_buffer)
+    oracle.guro(f.color_buffer, f.normals_buffer, [0.3, -0.2, 1])
     filler = AdvancedPixelBufferFiller(res, res, fov=45, tile=tile, pipeline=True)
     fused = Renderer(filler, light, None, res, res, on_device="fused")
     img = fused.render(_M(tri, col, nrm)).cpu().numpy()
@@ -1329,7 +1338,7 @@ def test_fused_renderer_small_model_then_larger_model(oracle):
         tri, col, nrm = scene(fixture)
         f = oracle.OracleFiller(256, 256, fov=45)
         f.render_arrays(tri, col, nrm)
-        light.draw_illumination(f.color_buffer, f.normals_buffer)
+        oracle.guro(f.color_buffer, f.normals_buffer, [0.3, -0.2, 1])
         img = r.render(_M(tri, col, nrm)).cpu().numpy()
         assert img.any()
         assert_bit_equal(img, f.color_buffer, f"fused render of {fixture}")
@@ -1533,3 +1542,35 @@ def test_device_model_stats_are_lazy():
         m.scale(0.5)                                # keep_position: needs the mean of the shifted vertices
     assert_bit_equal(dev._vertices.cpu().numpy(), host._vertices, "vertices after shift, shift, scale")
     assert_bit_equal(dev.get_mean_vertex(), host.get_mean_vertex(), "mean vertex")
+
+
+def test_device_model_stats_on_a_model_of_2_pow_24_vertices():
+    """The mean vertex is numpy's sequential float32 sum (rows one after another, the first row the
+    start value) divided by the count in float64: pinned above 2^24 vertices too, where the count
+    is no float32 any more and the accumulator has long stopped taking in small terms — and the
+    serial kernel has to stay usable (loads batched ahead of the additions)."""
+    import time
+    import torch
+    from cython3dmodelrenderer_amd.data_structures import DeviceModel, Model
+    rng = np.random.default_rng(33)
+    V = (1 << 24) + 5
+    vtx = (rng.standard_normal((V, 3), dtype=np.float32) * np.float32(3.0) + np.array([100.0, -7.0, 0.01], np.float32))
+    vtx[0] = [-0.0, 5.0, -3.0]
+    fcs = rng.integers(0, V, (64, 3)).astype(np.int32)
+    host = Model.__new__(Model)                      # (the host constructor's vertex normals are beside the point)
+    mean = vtx.mean(axis=0)
+    span = np.max(np.linalg.norm(vtx - mean, axis=-1))
+    dev = DeviceModel.__new__(DeviceModel)
+    from cython3dmodelrenderer_amd import _capi
+    dev._lib = _capi.load(); dev.device = torch.device("cuda:0")
+    dev._vertices = torch.from_numpy(vtx).to("cuda:0")
+    dev._stats = torch.zeros(4, dtype=torch.float32, device="cuda:0")
+    dev._stats_valid = False; dev._stats_host = None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got_mean, got_span = dev.get_mean_vertex(), dev.get_max_span()
+    dt = time.perf_counter() - t0
+    assert_bit_equal(got_mean, mean, "mean of 2^24 + 5 vertices")
+    assert np.float32(got_span).view(np.uint32) == np.float32(span).view(np.uint32)
+    assert dt < 5.0, f"crender_model_stats took {dt:.1f} s for {V} vertices"
+    del host, fcs

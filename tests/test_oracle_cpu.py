@@ -145,12 +145,38 @@ def test_reference_render_png_end_to_end(oracle):
     Model -> filler(1024, fov 45, 8 threads) -> GuroIllumination([0,0,1]) -> flip -> uint8).
     SURVEY.md section 4: the reference's own 8-thread race / compiler leave ~116 pixels undecided."""
     from PIL import Image
-    from cython3dmodelrenderer_amd.illumination import GuroIllumination
     tri, col, nrm = _scene("trex_inputs.npz")
     f = oracle.OracleFiller(1024, 1024, fov=45)
     f.render_arrays(tri, col, nrm)
-    GuroIllumination([0, 0, 1]).draw_illumination(f.color_buffer, f.normals_buffer)
+    oracle.guro(f.color_buffer, f.normals_buffer, [0, 0, 1])          # (the oracle's own restatement)
     mine_bgr = f.color_buffer[::-1].astype("uint8")
     ref_rgb = np.asarray(Image.open(os.path.join(GOLD, "reference_output_T-Rex.png")).convert("RGB"))
     differing = (mine_bgr[:, :, ::-1] != ref_rgb).any(axis=-1).sum()
     assert differing <= 200, differing
+
+
+def test_oracle_guro_matches_numpy_statements(oracle):
+    """The C restatement of guro_illumination.py:20-27 against the reference's own four numpy
+    statements, evaluated by numpy here (written out, not imported from the product package): bit
+    for bit on random, degenerate (zero normals), huge, tiny and NaN inputs."""
+    rng = np.random.default_rng(17)
+    n = (rng.standard_normal((64, 96, 3)) * 10 ** rng.uniform(-3, 3, (64, 96, 1))).astype(np.float32)
+    n[0, :8] = 0.0
+    n[1, :4] = np.nan
+    n[2, :4] = [1e30, -1e30, 1e30]
+    n[3, :4] = 1e-30
+    col = rng.uniform(0, 255, (64, 96, 3)).astype(np.float32)
+    for light in ([0, 0, 1], [0.3, -0.2, 1], [-1, 2, 0.5]):
+        want = col.copy()
+        light_direction = -np.asarray(light, dtype="float32")                      # :15-18
+        light_direction = light_direction / np.linalg.norm(light_direction)
+        with np.errstate(invalid="ignore", over="ignore"):
+            scalar_product = np.sum(n * light_direction, axis=-1, keepdims=True)   # :23
+            norm = np.linalg.norm(n, axis=-1, keepdims=True)                       # :24
+            shadow_coeff = scalar_product / (norm + 1e-6)                          # :25
+            shadow_coeff = np.clip(shadow_coeff, 0, 1)                             # :26
+            want *= shadow_coeff                                                   # :27
+        got = oracle.guro(col.copy(), n, light)
+        nan = np.isnan(want)
+        assert (np.isnan(got) == nan).all()
+        assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32)), light
