@@ -390,8 +390,8 @@ def main():
     if rank == 0:
         frames_per_step = 1 if (world == 1 or strips) else world
         fps = frames_per_step * args.steps / elapsed
-        rows = y1 - y0                               # this rank's strip (ranks are symmetric)
-        abytes = algorithmic_bytes(T, rows, W)
+        rows = filler.y1 - filler.y0                 # rows the measured launches rasterize: this rank's strip
+        abytes = algorithmic_bytes(T, rows, W)       # (ranks are symmetric), its first sub-strip with --chunks
         # Two views of the raster kernel's launch duration:
         #   raster_ms      HIP events right around the launch (second pass).  The event records
         #                  open idle bubbles in which the previous frame's dirty lines drain, so a

@@ -1572,5 +1572,6 @@ def test_device_model_stats_on_a_model_of_2_pow_24_vertices():
     dt = time.perf_counter() - t0
     assert_bit_equal(got_mean, mean, "mean of 2^24 + 5 vertices")
     assert np.float32(got_span).view(np.uint32) == np.float32(span).view(np.uint32)
+    print(f"crender_model_stats: {dt * 1e3:.1f} ms for {V} vertices")
     assert dt < 5.0, f"crender_model_stats took {dt:.1f} s for {V} vertices"
     del host, fcs
