@@ -125,7 +125,7 @@ class _Model:
         self._vertices_by_triangles, self._colors_by_triangles, self._normals_by_triangles = tri, col, nrm
 
 
-def api_calls(tri, col, nrm, H, W, fov, device, budget_s=6.0):
+def api_calls(tri, col, nrm, H, W, fov, device, budget_s=3.0):
     """The reference's OWN calls through the drop-in classes, model arrays in host numpy memory,
     results in host numpy memory where the reference returns them there — PCIe included:
       render_model(model)                       .pyx:92-104 (upload + K1 + K2, buffers composite)
