@@ -1499,23 +1499,29 @@ CR_DEV void build_order(const uint32_t *__restrict__ count, int ntx, int nty,
 // bunny 4096^2 and T-Rex 8192^2 are a few thousand triangles of thousands of pixels each: a tile
 // holds a handful of records that each cover much of it.  The block sweep above computes every
 // covered pixel's barycentrics twice (once for the depth key in LDS, once more in the resolve) and
-// pays an LDS atomic per fragment.  Here the tile's 1024 pixels are OWNED: thread t holds the four
-// x-neighbours (4 * (t & 7) .. + 3, row t >> 3) with their running minimum key AND the winning
-// fragment's barycentrics in registers; the wavefront (eight tile rows) walks the records in a
-// uniform loop, skipping records whose box misses its rows or whose triangle certainly misses its
-// rectangle (the block cull's corner test, raster_math.h (1), on the band), and the resolve only
-// interpolates: no LDS atomics, no second set of divisions, and a thread's four pixels leave as
-// 16-byte stores (z: one, colour and normal: three each).  Same device functions, same keys, same
-// tie rule as the sweeps above: the planes are bit-identical.
+// pays an LDS atomic per fragment.  Here the tile's 1024 pixels are OWNED: thread t holds four pixels
+// of row t >> 3 — x = (t & 7) + 8 j, so that pixel j of a wavefront's 64 lanes is the j-th 8 x 8 block
+// of its band of eight rows — with their running minimum key AND the winning fragment's
+// barycentrics in registers; the wavefront walks the records in a uniform loop, passing over
+// records whose triangle certainly misses its band (one word per record, worked out once by the
+// record's thread: the block cull's corner test, raster_math.h (1), on box ∩ band), and the
+// divisions of pixel j are skipped when none of the block's 64 pixels is a candidate — a triangle
+// that touches part of a band costs the blocks it touches (with a thread's pixels side by side,
+// every one of the four passes found SOME lane live: 466 k division passes per bunny frame
+// instead of 333 k; raster 149 -> 133 us).  The resolve only interpolates: no LDS atomics, no
+// second set of divisions.  Same device functions, same keys, same tie rule as the sweeps above:
+// the planes are bit-identical.
 constexpr uint32_t kOwnFast = 1u << 4;     // flags word of a record: bits 0..3 bands, 4 window, 5..10 signs
 template <bool CLEAR, typename I>
 CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const float *__restrict__ col, const float *__restrict__ nrm,
-                       const uint32_t *__restrict__ pos_of, const Light &Lt, bool vec,
+                       const uint32_t *__restrict__ pos_of, const Light &Lt,
                        float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
                        int32_t *__restrict__ win, int W, int X0, int Y0, int X1, int Y1)
 {
     const int tid = threadIdx.x;
-    const int Xs = X0 + ((tid & 7) << 2), Y = Y0 + (tid >> 3);
+    // a thread's four pixels lie 8 apart: pixel j of the wavefront's lanes is the j-th 8x8 block of its band
+    constexpr int XS = 8;
+    const int Xs = X0 + (tid & 7), Y = Y0 + (tid >> 3);
     const bool row_in = Y < Y1;
     const I pix0 = (I)((I)Y * (I)W + (I)Xs);
     unsigned long long best[4];
@@ -1524,7 +1530,7 @@ CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const flo
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         best[j] = make_key(zord(1e6f), KEY_LOW_PRIOR);
-        if (!CLEAR && row_in && Xs + j < X1) best[j] = make_key(zord_prior(*elem(zb, (I)(pix0 + j))), KEY_LOW_PRIOR);
+        if (!CLEAR && row_in && Xs + XS * j < X1) best[j] = make_key(zord_prior(*elem(zb, (I)(pix0 + XS * j))), KEY_LOW_PRIOR);
         w1[j] = w2[j] = w3[j] = 0.0f;
     }
     const uint32_t my_band = 1u << (tid >> 6);
@@ -1559,7 +1565,7 @@ CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const flo
         const float ry1 = st.l01 * (fy - st.y2), ry2 = st.l11 * (fy - st.y0), ry3 = st.l21 * (fy - st.y1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int x = Xs + j;
+            const int x = Xs + XS * j;
             const float fx = (float)x;
             const float n1 = ry1 - st.l02 * (fx - st.x2), n2 = ry2 - st.l12 * (fx - st.x0), n3 = ry3 - st.l22 * (fx - st.x1);
             const bool live = rows_ok && (unsigned)(x - bx0) < (unsigned)(bx1 - bx0) && !surely_outside(st, n1, n2, n3);
@@ -1625,24 +1631,14 @@ CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const flo
     }
     float *zp = elem(zb, pix0), *cp = elem(cb, (I)(pix0 * 3)), *np_ = elem(nb, (I)(pix0 * 3));
     int32_t *wp = win ? reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix0)) : nullptr;
-    const bool all4 = Xs + 4 <= X1 && (CLEAR || (have[0] && have[1] && have[2] && have[3]));
-    if (vec && all4) {
-        *reinterpret_cast<float4 *>(zp) = make_float4(zv[0], zv[1], zv[2], zv[3]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            reinterpret_cast<float4 *>(cp)[k] = make_float4(cv[4 * k], cv[4 * k + 1], cv[4 * k + 2], cv[4 * k + 3]);
-            reinterpret_cast<float4 *>(np_)[k] = make_float4(nv[4 * k], nv[4 * k + 1], nv[4 * k + 2], nv[4 * k + 3]);
-        }
-        if (wp) *reinterpret_cast<int4 *>(wp) = make_int4(iv[0], iv[1], iv[2], iv[3]);
-        return;
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (Xs + j >= X1 || !(CLEAR || have[j])) continue;
-        zp[j] = zv[j];
-        cp[3 * j] = cv[3 * j]; cp[3 * j + 1] = cv[3 * j + 1]; cp[3 * j + 2] = cv[3 * j + 2];
-        np_[3 * j] = nv[3 * j]; np_[3 * j + 1] = nv[3 * j + 1]; np_[3 * j + 2] = nv[3 * j + 2];
-        if (wp) wp[j] = iv[j];
+        if (Xs + XS * j >= X1 || !(CLEAR || have[j])) continue;
+        const int o = XS * j;
+        zp[o] = zv[j];
+        cp[3 * o] = cv[3 * j]; cp[3 * o + 1] = cv[3 * j + 1]; cp[3 * o + 2] = cv[3 * j + 2];
+        np_[3 * o] = nv[3 * j]; np_[3 * o + 1] = nv[3 * j + 1]; np_[3 * o + 2] = nv[3 * j + 2];
+        if (wp) wp[o] = iv[j];
     }
 }
 
@@ -2097,10 +2093,10 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                     }
                     __syncthreads();
                     if (L.addr32)
-                        owner_tile<CLEAR, uint32_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, L.vec_clear != 0, zb, cb, nb, win,
+                        owner_tile<CLEAR, uint32_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, zb, cb, nb, win,
                                                     G.W, X0, Y0, X1, Y1);
                     else
-                        owner_tile<CLEAR, size_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, L.vec_clear != 0, zb, cb, nb, win,
+                        owner_tile<CLEAR, size_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, zb, cb, nb, win,
                                                   G.W, X0, Y0, X1, Y1);
                     CR_STAMP(3);
                     return;

@@ -7,7 +7,6 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-api-calls > $OUT/be
 python bench.py --workload bunny4096 --steps 50 --warmup 5 --no-api-calls > $OUT/bench_bunny4096.json 2>/dev/null
 python bench.py --workload trex8192 --steps 30 --warmup 3 --no-api-calls > $OUT/bench_trex8192.json 2>/dev/null
 python bench.py --workload synth10m --steps 10 --warmup 2 --no-api-calls > $OUT/bench_synth10m.json 2>/dev/null
-python bench.py --workload synth10m --steps 10 --warmup 2 --no-api-calls --no-cpu-baseline --persistent off > $OUT/bench_synth10m_nopersist.json 2>/dev/null
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$OUT/bench_*.json")):
