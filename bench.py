@@ -376,6 +376,30 @@ def main():
         assert n_k == args.steps and not probe._pipe.overflowed(probe)
         del probe
 
+    # ---- strips: the SAME frame on ONE GPU, in the same run (rank 0; the others wait at the next
+    # collective): the denominator of this line's strong-scaling speedup.  The N = 1 line of bench.py
+    # is the headline workload (T-Rex 1024x1024), not this one, so a speedup computed from the two
+    # lines' values would compare different frames.
+    one_gpu = None
+    if strips and rank == 0:
+        solo = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile, pipeline=not args.no_pipeline)
+        solo.render_arrays(tri, col, nrm, clear=True)
+        solo.synchronize()
+        for _ in range(max(2, args.warmup)):
+            solo.render_frame()
+        solo.synchronize()
+        t5 = time.perf_counter()
+        for _ in range(args.steps):
+            solo.render_frame()
+        solo.join()
+        torch.cuda.synchronize(device)
+        dt1 = (time.perf_counter() - t5) / args.steps
+        assert not (solo._pipe is not None and solo._pipe.overflowed(solo))
+        one_gpu = {"n_gpus": 1, "value": 1.0 / dt1, "unit": "frames/s", "ms_per_step": dt1 * 1e3,
+                   "what": "the whole frame of this workload on rank 0's GPU alone, same process, same K "
+                           "(no exchange: the frame is complete in its memory)"}
+        del solo
+
     if world > 1:
         t = torch.tensor([elapsed, raster_ms, bin_ms, elapsed_render_only or 0.0, kframe_events_ms or 0.0,
                           kframe_b2b_ms or 0.0], dtype=torch.float64,
@@ -470,6 +494,9 @@ def main():
                          "traffic": load_traffic(args.workload) if rows == H else None},
             "bin_entries": {"needed": need, "capacity": cap},
         }
+        if one_gpu is not None:
+            one_gpu["speedup_of_this_line"] = fps / one_gpu["value"]
+            out["strong_scaling_reference"] = one_gpu
         if args.workload == "synth10m":
             out["config"]["resident_model"] = (
                 "sorted ONCE at upload into tile-coherent order (Morton code of the 32-pixel tile of each "

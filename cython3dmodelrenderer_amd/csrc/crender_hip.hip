@@ -1565,6 +1565,7 @@ CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const flo
         const float ry1 = st.l01 * (fy - st.y2), ry2 = st.l11 * (fy - st.y0), ry3 = st.l21 * (fy - st.y1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (X0 + XS * j >= bx1 || X0 + XS * j + XS <= bx0) continue;     // the box misses block j (uniform)
             const int x = Xs + XS * j;
             const float fx = (float)x;
             const float n1 = ry1 - st.l02 * (fx - st.x2), n2 = ry2 - st.l12 * (fx - st.x0), n3 = ry3 - st.l22 * (fx - st.x1);
