@@ -820,7 +820,11 @@ __global__ __launch_bounds__(kWave) void k_count_wave(const float *__restrict__ 
 
 // The fill pass in the same shape: (A) the wavefront's entries per tile in LDS, (B) one returning
 // atomic per touched tile on the list's cursor reserves a run, (C) LDS cursors hand out its slots.
-// trange is read once (k_fill's block histograms need two sweeps).
+// trange is read once (k_fill's block histograms need two sweeps).  The pass is a latency chain —
+// ranges, then offsets + returning atomics, then the entries: three memory round trips per wavefront,
+// 8 192 wavefronts resident — so a wavefront takes kFillPer x 64 triangles through each round trip
+// together (10 M triangles: 97 -> 78 us with two, 77 with four; profiles/r03/ab_fill_groups.txt).
+constexpr int kFillPer = 2;
 __global__ __launch_bounds__(kWave) void k_fill_wave(const uint2 *__restrict__ trange,
                                                      const uint32_t *__restrict__ offs,
                                                      uint32_t *__restrict__ cursor,
@@ -829,26 +833,37 @@ __global__ __launch_bounds__(kWave) void k_fill_wave(const uint2 *__restrict__ t
 {
     __shared__ uint32_t hist[kWaveHistTiles];
     const int lane = threadIdx.x;
-    const int64_t b0 = (int64_t)blockIdx.x * kWave;
-    uint2 r = (b0 + lane < T) ? trange[b0 + lane] : make_uint2(kNoTiles, 0);
+    const int64_t b0 = (int64_t)blockIdx.x * (kWave * kFillPer);
+    uint2 r[kFillPer];
+#pragma unroll
+    for (int p = 0; p < kFillPer; ++p)
+        r[p] = (b0 + p * kWave + lane < T) ? trange[b0 + p * kWave + lane] : make_uint2(kNoTiles, 0);
 #pragma unroll
     for (int i = 0; i < kWaveHistTiles / kWave; ++i) hist[i * kWave + lane] = 0;   // (while the ranges are on their way)
     int X0 = 0x7FFFFFFF, X1 = -1, Y0 = 0x7FFFFFFF, Y1 = -1;
-    if (r.x != kNoTiles) {
-        X0 = r.x & 0xFFFF; X1 = r.x >> 16; Y0 = r.y & 0xFFFF; Y1 = r.y >> 16;
+#pragma unroll
+    for (int p = 0; p < kFillPer; ++p) {
+        if (r[p].x != kNoTiles) {
+            const int x0 = r[p].x & 0xFFFF, x1 = r[p].x >> 16, y0 = r[p].y & 0xFFFF, y1 = r[p].y >> 16;
+            X0 = x0 < X0 ? x0 : X0; X1 = x1 > X1 ? x1 : X1; Y0 = y0 < Y0 ? y0 : Y0; Y1 = y1 > Y1 ? y1 : Y1;
+        }
     }
     wave_box(X0, X1, Y0, Y1);
     if (X1 < 0) return;
     const int bw = X1 - X0 + 1, area = bw * (Y1 - Y0 + 1);
     if (area > kWaveHistTiles) {
-        for_each_tile(r, (uint32_t)(b0 + lane), G.ntx, [&](int tile, uint32_t id) {
-            const uint32_t pos = offs[tile] + atomicAdd(&cursor[tile], 1u);
-            if (pos < capacity) entries[pos] = id;
-        });
+#pragma unroll
+        for (int p = 0; p < kFillPer; ++p)
+            for_each_tile(r[p], (uint32_t)(b0 + p * kWave + lane), G.ntx, [&](int tile, uint32_t id) {
+                const uint32_t pos = offs[tile] + atomicAdd(&cursor[tile], 1u);
+                if (pos < capacity) entries[pos] = id;
+            });
         return;
     }
     __syncthreads();
-    for_each_tile_xy(r, [&](int tx, int ty, int) { atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u); });
+#pragma unroll
+    for (int p = 0; p < kFillPer; ++p)
+        for_each_tile_xy(r[p], [&](int tx, int ty, int) { atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u); });
     __syncthreads();
     {
         constexpr int kRounds = kWaveHistTiles / kWave;
@@ -873,10 +888,12 @@ __global__ __launch_bounds__(kWave) void k_fill_wave(const uint2 *__restrict__ t
             if (c[k]) hist[k * kWave + lane] = base[k];
     }
     __syncthreads();
-    for_each_tile_xy(r, [&](int tx, int ty, int owner) {
-        const uint32_t pos = atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u);
-        if (pos < capacity) entries[pos] = (uint32_t)(b0 + owner);
-    });
+#pragma unroll
+    for (int p = 0; p < kFillPer; ++p)
+        for_each_tile_xy(r[p], [&](int tx, int ty, int owner) {
+            const uint32_t pos = atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u);
+            if (pos < capacity) entries[pos] = (uint32_t)(b0 + p * kWave + owner);
+        });
 }
 
 // Exclusive scan of count[0..ntiles) into offs[0..ntiles]; count is zeroed (k_fill uses
@@ -3024,7 +3041,7 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
                 if (attr != hipSuccess) return fail_hip(attr, "hipFuncSetAttribute(k_fill)");
             }
             if (wave_scan)
-                hipLaunchKernelGGL(k_fill_wave, dim3((unsigned)((T + kWave - 1) / kWave)), dim3(kWave), 0, s,
+                hipLaunchKernelGGL(k_fill_wave, dim3((unsigned)((T + kWave * kFillPer - 1) / (kWave * kFillPer))), dim3(kWave), 0, s,
                                    plan->trange(), plan->offs(), count, plan->entries(),
                                    (uint32_t)L.capacity, T, G);
             else if (lds_hist)

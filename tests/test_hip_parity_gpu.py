@@ -1575,3 +1575,32 @@ def test_device_model_stats_on_a_model_of_2_pow_24_vertices():
     print(f"crender_model_stats: {dt * 1e3:.1f} ms for {V} vertices")
     assert dt < 5.0, f"crender_model_stats took {dt:.1f} s for {V} vertices"
     del host, fcs
+
+
+def test_device_model_transformed_between_pipelined_frames(oracle):
+    """The documented protocol for changing a resident DeviceModel under a swap chain: join, transform
+    (the kernels rewrite the arrays in place on the current stream), hand the model to render_model
+    again (re-binds every slot: what was binned ahead from the old vertices is dropped), go on."""
+    from cython3dmodelrenderer_amd.data_structures import DeviceModel, Model
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    from cython3dmodelrenderer_amd.scenes import fit_model
+    rng = np.random.default_rng(41)
+    V, T = 900, 2500
+    vertices = rng.standard_normal((V, 3)).astype(np.float32)
+    faces = rng.integers(0, V, (T, 3)).astype(np.int32)
+    host, dev = Model(vertices, faces), DeviceModel(Model(vertices, faces))
+    for m in (host, dev):
+        m.set_uniform_color()
+        fit_model(m)
+    filler = AdvancedPixelBufferFiller(256, 256, fov=45, pipeline=True)
+    for step, move in enumerate(([0.0, 0.0, 0.0], [0.2, -0.1, 0.3], [-0.35, 0.2, 0.1])):
+        filler.join()
+        for m in (host, dev):
+            m.shift(np.array(move, np.float32))
+        filler.render_model(dev, clear=True)
+        for _ in range(5):
+            filler.render_frame()
+        f = oracle.OracleFiller(256, 256, fov=45)
+        f.render_model(host)
+        assert_bit_equal(filler.get_z_buffer(), f.z_buffer, f"z after move {step}")
+        assert_bit_equal(filler.get_color_buffer(), f.color_buffer, f"colour after move {step}")
