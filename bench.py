@@ -190,6 +190,9 @@ def main():
                          "(configs[3], the sharded frame) on several")
     ap.add_argument("--synth-triangles", type=int, default=10_000_000)
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--pipeline-tile", type=int, default=0,
+                    help="tile size of the swap chain's plans when it should differ from --tile (throughput "
+                         "against single-frame latency: DESIGN.md section 6)")
     ap.add_argument("--max-triangles", type=int, default=-1,
                     help="experiment knob: keep only the first N triangles (0 = pure clear)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -270,7 +273,7 @@ def main():
         sr = None
         filler = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile,
                                            pipeline=not args.no_pipeline,
-                                           pipeline_depth=args.pipeline_depth,
+                                           pipeline_depth=args.pipeline_depth, pipeline_tile=args.pipeline_tile,
                                            lookahead={"auto": None, "on": True, "off": False}[args.lookahead])
 
     def step(pipelined=True, gather=True):
@@ -353,7 +356,7 @@ def main():
     lookahead = filler._pipe is not None and filler._pipe.lookahead
     kframe_events_ms = kframe_b2b_ms = None
     if lookahead:
-        probe = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile, pipeline=True,
+        probe = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.pipeline_tile or args.tile, pipeline=True,
                                           pipeline_depth=1, lookahead=True,
                                           row_strip=(y0, y1) if strips else None)
         probe.render_arrays(tri, col, nrm, clear=True)
@@ -426,7 +429,7 @@ def main():
         # The roofline uses the LONGER of the two, i.e. never the flattering one.
         single_ms = elapsed_single / args.steps * 1e3
         raster_b2b_ms = max(single_ms - bin_ms, 0.0)
-        ts = filler.tile or (16 if H * W <= 1024 * 1024 else 32)
+        ts = (args.pipeline_tile if lookahead and args.pipeline_tile else filler.tile) or (16 if H * W <= 1024 * 1024 else 32)
         if lookahead:
             kernel = f"k_frame<{ts},true>"
             views = {"hip_events_around_each_launch": kframe_events_ms, "frames_back_to_back_on_one_stream": kframe_b2b_ms}
@@ -460,7 +463,7 @@ def main():
                                      f"all-gather, exchange = {args.exchange}, {args.chunks} sub-strip(s) per rank, "
                                      f"projection = {'rank 0, broadcast of the projected vertices' if args.project == 'broadcast' else 'every rank its own (model replicated)'}"
                                      if strips else "independent full frames per rank, no collective"),
-                       "tile": filler.tile or "auto",
+                       "tile": filler.tile or "auto", "pipeline_tile": args.pipeline_tile or "same",
                        "frame": "clear + project + rasterize, model resident in HBM",
                        "pipelined": (False if args.no_pipeline else
                                      f"swap chain of {filler._pipeline_depth} (GPU_MAX_HW_QUEUES="
