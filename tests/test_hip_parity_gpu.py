@@ -1623,3 +1623,21 @@ def test_swap_chain_with_its_own_tile_size(oracle):
         assert_bit_equal(filler.get_normals_buffer(), f.normals_buffer, "normal")
         assert_bit_equal(filler.get_winner_tensor().cpu().numpy(), f.winner, "winner")
     assert filler._pipe is not None and filler._pipe.lookahead
+
+
+@pytest.mark.parametrize("name,fixture,res", [("bunny4096", "bunny_inputs.npz", 4096), ("trex8192", "trex_inputs.npz", 8192)])
+def test_full_size_idempotence_and_strips_through_the_pixel_owners(hip, golden, name, fixture, res):
+    """Size-independent properties at BASELINE.json's full sizes on the path these frames take (32-pixel
+    tiles, pixel owners): drawing the same model again on top of the finished frame (compositing: every
+    fragment ties with the prior value and must overwrite it with identical bits) changes nothing, and
+    the frame assembled from 5 ragged row strips equals the whole one — all against the golden hashes."""
+    tri, col, nrm = scene(fixture)
+    g = golden["scenes"][name]
+    got = gpu_frame(hip, tri, col, nrm, res, res, mode="fused", clear=True)
+    assert (sha(got[0]), sha(got[1]), sha(got[2])) == (g["z"], g["c"], g["n"])
+    twice = gpu_frame(hip, tri, col, nrm, res, res, mode="fused", prior=got[:3])
+    assert (sha(twice[0]), sha(twice[1]), sha(twice[2])) == (g["z"], g["c"], g["n"]), "idempotence"
+    cuts = [0, res // 7 + 3, res // 3, res // 2 + 17, res - 29, res]
+    strips = list(zip(cuts, cuts[1:]))
+    parts = gpu_frame(hip, tri, col, nrm, res, res, mode="fused", strips=strips, clear=True)
+    assert (sha(parts[0]), sha(parts[1]), sha(parts[2])) == (g["z"], g["c"], g["n"]), "ragged strips"
