@@ -31,6 +31,7 @@ for w in ${WORKLOADS:-trex1024}; do
         out=/tmp/abv/prof_${name}_$g; rm -rf $out
         (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $REPO/bench.py --workload $w --steps 100 --warmup 3 --no-cpu-baseline --no-api-calls --no-pipeline > $out.log 2>&1
          TMPDIR=/tmp rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_BUSY_CYCLES --output-format csv -d $out/pmc_sq -- python3 $REPO/bench.py --workload $w --steps 50 --warmup 3 --no-cpu-baseline --no-api-calls --no-pipeline >> $out.log 2>&1)
+        [ -n "${PROF2:-}" ] && (cd /tmp && TMPDIR=/tmp rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_lds -- python3 $REPO/bench.py --workload $w --steps 50 --warmup 3 --no-cpu-baseline --no-api-calls --no-pipeline >> $out.log 2>&1)
         python scripts/summarize_prof.py $out 2>/dev/null | grep -E "^k_|^## kernel" | sed "s/^/   [$name dbg=$g] /"
       fi
     done
