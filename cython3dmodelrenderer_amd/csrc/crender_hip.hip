@@ -29,8 +29,7 @@
 //   block, 8192 large-record sweep for every batch (32/64-pixel tiles), bits 16..23 = n + 1:
 //   pixel-parallel path of 16-pixel tiles for batches <= n records (n = 0 disables it; default
 //   kPixelPathRecords), 16384 frames of a swap chain are treated as lone frames (ordered dispatch
-//   and split tiles although they overlap), 32768 no pixel-owner sweep on 32-pixel tiles,
-//   1 << 28 no per-wavefront sweep (scan-path frames on 32-pixel tiles launch the plain k_raster).
+//   and split tiles although they overlap), 32768 no pixel-owner sweep on 32-pixel tiles.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -80,14 +79,7 @@ constexpr int kThreads = 256;           // 4 wavefronts per workgroup
 // CU instead of 5: bunny 4096^2 +5 %, T-Rex 8192^2 raster 0.381 -> 0.341 ms; the fused-clear
 // instantiation fits without spilling, the compositing one spills 4 registers).  The 64-pixel
 // kernel is limited by its 48 KB of LDS, not by registers.  (r01 A/B, same box.)
-#ifndef CR_WPS32
-#define CR_WPS32 6
-#endif
-constexpr int kWavesPerSimd16 = 7, kWavesPerSimd32 = CR_WPS32;
-#ifndef CR_WPS_WAVES
-#define CR_WPS_WAVES 4
-#endif
-constexpr int kWavesPerSimdWaves = CR_WPS_WAVES;   // k_raster<32, ., WAVES>: LDS allows four workgroups per CU   // (32-pixel tiles: 28.7 KB of LDS = 5 workgroups per CU)
+constexpr int kWavesPerSimd16 = 7, kWavesPerSimd32 = 6;   // (32-pixel tiles: 28.7 KB of LDS = 5 workgroups per CU)
 constexpr int kItemPixels = 2;      // samples per work item of the per-pixel sweep of 16-pixel tiles
 constexpr int kItemPixels32 = 2;    // the same for the small-record batches of 32-pixel tiles
 constexpr uint32_t kPixelPathRecords = 8;   // k_raster<16>: batches this short go pixel-parallel
@@ -1092,188 +1084,6 @@ struct WorkQueue {
     uint32_t wave_px[kThreads / 64];
 };
 
-// ---- wave sweep: tiles of SMALL records on 32-pixel tiles (the 10 M-triangle frame) -----------------
-// The per-pixel sweep flattens a batch's samples over the 256 threads, and every work item then has
-// to FIND its record (a binary search of the prefix sums: 6-7 dependent LDS reads), load it (14
-// words), redo what depends on the triangle alone and divide three times for a sample that lies
-// outside the triangle two times out of three: ~200 vector instructions per pair of samples, and
-// k_raster on 10 M small triangles issues a vector instruction on 95 % of its SIMD cycles
-// (SQ_ACTIVE_INST_VALU over 1024 SIMDs against the launch's cycles, profiles/r03) — the only
-// lever is the instruction count.  Here every WAVEFRONT works for itself, without a workgroup
-// barrier between the tile's first batch and the resolve: it takes 64 records of every 256 of the
-// tile's list and keeps them in LDS of its own.
-//  * Records are set up ONCE by their lane (edge constants, reciprocals) and stored compacted
-//    (records without work take no slot).
-//  * Their work is flattened into ITEMS of four x-neighbours of a box row.  Which record owns item
-//    i comes from a table, not from a search: every record marks its first item in a byte array
-//    and one prefix sum over the marks (eight bytes per lane, in registers) turns them into owners.
-//  * PHASE 1, one item per lane and trip: the three numerators of mu.pyx:34 for the item's four
-//    samples in PACKED f32 arithmetic (v_pk_add_f32 / v_pk_mul_f32: two IEEE binary32 operations
-//    per lane and instruction at ~1.1x the issue cost of one, scripts/ubench/valu_rate.hip; the
-//    very operations of numerators(), component by component) and the exact sign rejection of
-//    raster_math.h (1).  The survivors — the triangle's pixels and a few beside its edges, a
-//    third of the box — are appended to a ring in LDS (numerators, record slot, pixel).
-//  * PHASE 2 runs whenever the ring holds 64 candidates: every lane takes one — quotients(), the
-//    b < 0 test, z, the depth key, ds_min_u64 — at full density instead of one live lane in three.
-// Perfectly balanced whatever the box sizes (a lane-per-record variant with an in-batch counting
-// sort was tried first: fewer instructions than the old sweep, but slower, every wavefront waiting
-// at the batch's barriers for the one the sort had handed the longest records —
-// profiles/r04/ab_lane_per_record_sorted_synth10m.txt).  Same device functions, same keys, same
-// tie rule: the planes are bit-identical to the other sweeps'.
-constexpr int kRing = 128;               // candidates per ring (a push adds <= 64 to < 64 left over)
-constexpr uint32_t kOwnerChunk = 512;    // items per owner table: eight bytes per lane
-struct WaveLds {                         // one per wavefront
-    float4 p1[64][3];                    // phase 1: x0 y0 x1 y1 | x2 y2 1/quads-per-row, first item | box | rej1 rej2 rej3 -
-    float p2[64][10];                    // phase 2: l03 l13 l23 r1 r2 r3 z0 z1 z2 key_low
-    unsigned char owner[kOwnerChunk];    // record slot of every item of the chunk
-    float ring[4][kRing];                // n1[], n2[], n3[], (slot << 10 | pixel)[]
-};
-static_assert(sizeof(WaveLds) == 8192, "four of them beside the key plane: 40 KB, four workgroups per CU");
-
-typedef float cr_v2f __attribute__((ext_vector_type(2)));
-CR_DEV cr_v2f splat2(float a) { return cr_v2f{a, a}; }
-
-// One sub-batch: the wavefront's 64 lanes come with a record each (`have`; t, low = low word of its
-// depth keys, boxp = tile-local packed box as in WorkQueue::box, 0 = no work).  key: the tile's plane.
-CR_DEV void wave_sweep(WaveLds &wl, unsigned long long *key, bool have, const TriXYZ &t, uint32_t low,
-                       uint32_t boxp, int X0, int Y0, int lane, int dbg)
-{
-    constexpr int TS = 32;
-    const uint32_t bx = boxp & 63u, by = (boxp >> 6) & 63u, bw = (boxp >> 12) & 127u, bh = boxp >> 19;
-    const uint32_t nq = (bw + 3u) >> 2;                     // items per box row
-    const uint32_t P = have ? nq * bh : 0u;                 // items of this record (<= 8 x 32)
-    const unsigned long long nz = __builtin_amdgcn_ballot_w64(P != 0u);
-    if (nz == 0ull) return;                                 // (uniform)
-    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
-    const uint32_t incl = wave_incl_sum(P);
-    const uint32_t S = incl - P;                            // the record's first item
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if (P != 0u) {
-        const TriSetup st = make_setup(t, true);
-        const uint32_t w = S | ((bw - 1u) << 15) | (bx << 20) | (by << 25);
-        wl.p1[slot][0] = make_float4(st.x0, st.y0, st.x1, st.y1);
-        wl.p1[slot][1] = make_float4(st.x2, st.y2, __builtin_amdgcn_rcpf((float)nq), __uint_as_float(w));
-        wl.p1[slot][2] = make_float4(st.rej1, st.rej2, st.rej3, 0.0f);
-        float *c = wl.p2[slot];
-        c[0] = st.l03; c[1] = st.l13; c[2] = st.l23;
-        c[3] = st.fast ? st.r1 : 0.0f; c[4] = st.r2; c[5] = st.r3;
-        c[6] = st.z0; c[7] = st.z1; c[8] = st.z2; c[9] = __uint_as_float(low);
-    }
-    float *rn1 = wl.ring[0], *rn2 = wl.ring[1], *rn3 = wl.ring[2];
-    uint32_t *rd = reinterpret_cast<uint32_t *>(wl.ring[3]);
-    uint32_t head = 0, tail = 0;       // (wavefront-uniform)
-
-    // phase 2: the first n (<= 64) candidates of the ring, one per lane — .pyx:215-223 from the numerators on
-    auto consume = [&](uint32_t n) {
-        __builtin_amdgcn_wave_barrier();
-        if ((uint32_t)lane < n && !(dbg & (1 << 29))) {      // (1 << 29: ablation, no phase 2)
-            const uint32_t e = (head + (uint32_t)lane) & (kRing - 1);
-            const float n1 = rn1[e], n2 = rn2[e], n3 = rn3[e];
-            const uint32_t d = rd[e];
-            const float *c = wl.p2[d >> 10];
-            TriSetup s;
-            s.l03 = c[0]; s.l13 = c[1]; s.l23 = c[2]; s.r1 = c[3]; s.r2 = c[4]; s.r3 = c[5];
-            s.z0 = c[6]; s.z1 = c[7]; s.z2 = c[8];
-            s.fast = s.r1 != 0.0f;
-            float b1, b2, b3;
-            quotients(s, n1, n2, n3, true, b1, b2, b3);
-            if (!(b1 < 0.0f || b2 < 0.0f || b3 < 0.0f)) {                   // .pyx:215-216 (NaN passes)
-                const float z = interp(s.z0, s.z1, s.z2, b1, b2, b3);
-                if (z == z)                                                 // .pyx:220
-                    lds_key_min(&key[d & 1023u], make_key(zord(z), __float_as_uint(c[9])));
-            }
-        }
-        head += n;
-        __builtin_amdgcn_wave_barrier();
-    };
-    // (cand: the lanes of `m`)
-    auto push = [&](unsigned long long m, bool cand, float n1, float n2, float n3, uint32_t d) {
-        if (dbg & (1 << 30)) return;                              // (ablation: candidates dropped)
-        if (cand) {
-            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, tail));
-            const uint32_t e = at & (kRing - 1);
-            rn1[e] = n1; rn2[e] = n2; rn3[e] = n3; rd[e] = d;
-        }
-        tail += (uint32_t)__popcll(m);
-        if (tail - head >= 64u) consume(64u);
-    };
-
-    uint2 *ow2 = reinterpret_cast<uint2 *>(wl.owner);
-    for (uint32_t c0 = 0; c0 < total; c0 += kOwnerChunk) {
-        // ---- owners of the items [c0, c0 + 512): marks, then a prefix sum over them
-        ow2[lane] = make_uint2(0u, 0u);
-        __builtin_amdgcn_wave_barrier();
-        if (P != 0u && S - c0 < kOwnerChunk) wl.owner[S - c0] = 1;      // (S < c0 wraps to a huge value)
-        __builtin_amdgcn_wave_barrier();
-        uint2 f = ow2[lane];
-        f.x += f.x << 8; f.x += f.x << 16;                               // byte k = marks among the lane's items 0..k
-        f.y += f.y << 8; f.y += f.y << 16;
-        uint32_t rep = __umul24(f.x >> 24, 0x0101u);
-        f.y += rep | (rep << 16);
-        const uint32_t mine = f.y >> 24;
-        const uint32_t before = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(P != 0u && S < c0));
-        // owner = (records that begin before the item's lane) + (marks up to the item) - 1; every byte
-        // of the sum below is >= 1 where the item exists, so the subtraction borrows nothing
-        rep = __umul24(before + wave_incl_sum(mine) - mine, 0x0101u);
-        rep |= rep << 16;
-        f.x = f.x + rep - 0x01010101u;
-        f.y = f.y + rep - 0x01010101u;
-        ow2[lane] = f;
-        __builtin_amdgcn_wave_barrier();
-        // ---- phase 1 over the chunk's items, one per lane and trip (the next trip's record is on its
-        // way from LDS while this one's samples are evaluated)
-        const uint32_t cend = total - c0 < kOwnerChunk ? total - c0 : kOwnerChunk;
-        auto fetch = [&](uint32_t i, uint32_t &o, float4 &A, float4 &B, float4 &C) {
-            o = i < cend ? (uint32_t)wl.owner[i] : 0u;
-            A = wl.p1[o][0]; B = wl.p1[o][1]; C = wl.p1[o][2];
-        };
-        uint32_t o;
-        float4 A, B, C;
-        fetch((uint32_t)lane, o, A, B, C);
-        for (uint32_t i0 = 0; i0 < cend; i0 += 64u) {
-            const uint32_t i = i0 + (uint32_t)lane;
-            const unsigned long long act = __builtin_amdgcn_ballot_w64(i < cend);
-            const uint32_t w = __float_as_uint(B.w);
-            const uint32_t k = c0 + i - (w & 0x7FFFu);                   // item within its record
-            const uint32_t bwm1 = (w >> 15) & 31u;
-            const uint32_t row = (uint32_t)(((float)k + 0.5f) * B.z);    // k / quads per row (k < 256, <= 8 per row)
-            const uint32_t px = (k - __umul24(row, (bwm1 + 4u) >> 2)) << 2;
-            const uint32_t x = ((w >> 20) & 31u) + px, y = (w >> 25) + row;      // tile-local
-            const float fx0 = (float)(X0 + (int)x), fy = (float)(Y0 + (int)y);
-            const uint32_t d = (o << 10) | (y * TS + x);
-            // numerators(): l1 * (fy - ya) - l2 * (fx - xb), mu.pyx:34, for four x-neighbours
-            const float l01 = A.z - B.x, l02 = A.w - B.y, l11 = B.x - A.x, l12 = B.y - A.y, l21 = A.x - A.z, l22 = A.y - A.w;
-            const float a1 = l01 * (fy - B.y), a2 = l11 * (fy - A.y), a3 = l21 * (fy - A.w);
-            const cr_v2f fxa = {fx0, fx0 + 1.0f}, fxb = fxa + splat2(2.0f);
-            const cr_v2f n1a = splat2(a1) - splat2(l02) * (fxa - splat2(B.x)), n1b = splat2(a1) - splat2(l02) * (fxb - splat2(B.x));
-            const cr_v2f n2a = splat2(a2) - splat2(l12) * (fxa - splat2(A.x)), n2b = splat2(a2) - splat2(l12) * (fxb - splat2(A.x));
-            const cr_v2f n3a = splat2(a3) - splat2(l22) * (fxa - splat2(A.z)), n3b = splat2(a3) - splat2(l22) * (fxb - splat2(A.z));
-            // surely_outside() as a minimum (a NaN product drops out of v_min3 as it fails `<`)
-            const cr_v2f m1a = n1a * splat2(C.x), m2a = n2a * splat2(C.y), m3a = n3a * splat2(C.z);
-            const cr_v2f m1b = n1b * splat2(C.x), m2b = n2b * splat2(C.y), m3b = n3b * splat2(C.z);
-            const float lo0 = fminf(fminf(m1a.x, m2a.x), m3a.x), lo1 = fminf(fminf(m1a.y, m2a.y), m3a.y);
-            const float lo2 = fminf(fminf(m1b.x, m2b.x), m3b.x), lo3 = fminf(fminf(m1b.y, m2b.y), m3b.y);
-            const uint32_t room = bwm1 - px;        // samples 0..room of the item lie in the box
-            const bool c0_ = !(lo0 < -kRejTiny), c1_ = !(lo1 < -kRejTiny), c2_ = !(lo2 < -kRejTiny), c3_ = !(lo3 < -kRejTiny);
-            const bool r1_ = room >= 1u, r2_ = room >= 2u, r3_ = room >= 3u;
-            const unsigned long long k0 = act & __builtin_amdgcn_ballot_w64(c0_);
-            const unsigned long long k1 = act & __builtin_amdgcn_ballot_w64(c1_) & __builtin_amdgcn_ballot_w64(r1_);
-            const unsigned long long k2 = act & __builtin_amdgcn_ballot_w64(c2_) & __builtin_amdgcn_ballot_w64(r2_);
-            const unsigned long long k3 = act & __builtin_amdgcn_ballot_w64(c3_) & __builtin_amdgcn_ballot_w64(r3_);
-            const bool in = i < cend;
-            uint32_t o_n;
-            float4 A_n, B_n, C_n;
-            fetch(i + 64u, o_n, A_n, B_n, C_n);
-            push(k0, in && c0_, n1a.x, n2a.x, n3a.x, d);
-            push(k1, in && c1_ && r1_, n1a.y, n2a.y, n3a.y, d + 1u);
-            push(k2, in && c2_ && r2_, n1b.x, n2b.x, n3b.x, d + 2u);
-            push(k3, in && c3_ && r3_, n1b.y, n2b.y, n3b.y, d + 3u);
-            o = o_n; A = A_n; B = B_n; C = C_n;
-        }
-    }
-    if (tail != head) consume(tail - head);
-}
-
 // 16-pixel tiles keep a batch's records array-of-structures with everything that depends on the
 // triangle alone worked out ONCE by the record's thread: the nine edge constants of mu.pyx:11-21
 // and the refined reciprocals of the three denominators (raster_math.h (2)).  A sample then costs
@@ -1851,16 +1661,15 @@ CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const flo
 }
 
 // the batch: records array-of-structures on 16-pixel tiles (Rec16), else the WorkQueue
-template <int TS, bool WAVES = false>
+template <int TS>
 constexpr size_t raster_queue_bytes()
 {
-    if (WAVES) return sizeof(WaveLds) * (kThreads / 64) > sizeof(WorkQueue) ? sizeof(WaveLds) * (kThreads / 64) : sizeof(WorkQueue);
     return TS == 16 ? sizeof(Rec16) * kBatch16 + sizeof(uint32_t) * (kThreads + 8) : sizeof(WorkQueue);
 }
 
 // Workgroup `b` of a raster launch (the kernels below hand in their LDS: k_frame runs binning
 // wavefronts of another frame in the same launch).
-template <int TS, bool CLEAR, bool WAVES = false>
+template <int TS, bool CLEAR>
 CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict__ col,
                         const float *__restrict__ nrm, const TileLists &L,
                         float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
@@ -2060,9 +1869,9 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     }
 #endif
 
-    // the current record's pixel box clipped to this workgroup's rectangle (wh = 0: no work)
-    auto clip_current = [&](uint32_t &box_xy, uint32_t &box_wh) {
-        box_xy = 0; box_wh = 0;
+    for (uint32_t base = beg; base < end; base += kBatch) {
+        // ---- queue this batch: one record per thread, slot = thread index --------------
+        uint32_t box_xy = 0, box_wh = 0;
         if (cur_ok) {
             int xl = (int)(cur_bx & 0xFFFF), xr = (int)(cur_bx >> 16);
             int yt = (int)(cur_by & 0xFFFF), yb = (int)(cur_by >> 16);
@@ -2082,12 +1891,6 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                     box_wh = 0;
             }
         }
-    };
-
-    for (uint32_t base = beg; base < end; base += kBatch) {
-        // ---- queue this batch: one record per thread, slot = thread index --------------
-        uint32_t box_xy = 0, box_wh = 0;
-        clip_current(box_xy, box_wh);
         const uint32_t key_low = slotted ? ((0xFFFFu - (cur_id & 0xFFFFu)) << 16) | ((((base - beg) / kBatch) & 0xFFu) << 8) | (uint32_t)tid
                                          : 0xFFFFFFFEu - cur_id;
 #ifdef CRENDER_STAMPS
@@ -2175,63 +1978,6 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             const uint32_t blk_excl = incl - my_blocks;
             bool small_by_pixel = false;    // 32-pixel tiles: small records go per pixel too
             if constexpr (either) small_by_pixel = total < 16 * nrec && !(dbg & 8192);
-            if constexpr (WAVES) {
-                // A tile of small records (its first batch says so): from here to the resolve every
-                // wavefront sweeps its own 64 records of each batch of 256, in LDS of its own, without
-                // a workgroup barrier (wave_sweep).
-                if (base == beg && small_by_pixel && !(dbg & (1 << 28))) {
-                    if ((dbg & (1 << 27)) && blockIdx.x < 1024u) {      // (development: stagger the first workgroups of every CU)
-                        const uint32_t part = (blockIdx.x >> 8) & 3u;
-                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
-                        while (__builtin_amdgcn_s_memrealtime() - t0 < part * 1100ull) __builtin_amdgcn_s_sleep(32);
-                    }
-                    init_keys();
-                    __syncthreads();       // (and every wavefront has read the queue's totals: its memory is free)
-                    WaveLds &wl = reinterpret_cast<WaveLds *>(qraw)[wave];
-                    // Two batches ahead: the list entry (a triangle index) of the batch after next is on
-                    // its way while the next batch's record is gathered with the index that arrived
-                    // during the previous sweep — one memory round trip per sweep instead of the chain
-                    // entry -> record (a sweep of 64 small records is about as long as one round trip).
-                    auto entry_at = [&](uint32_t idx) { return idx < end ? L.entries[idx] : 0xFFFFFFFFu; };
-                    uint32_t nid = entry_at(beg + kBatch + (uint32_t)tid);
-                    float touch0 = 0.0f, touch1 = 0.0f, touch2 = 0.0f, touch3 = 0.0f;
-                    for (uint32_t b0 = beg;;) {
-                        const bool have = cur_ok && box_wh != 0;
-                        const TriXYZ t = cur_t;
-                        const uint32_t low = 0xFFFFFFFEu - cur_id;
-                        const uint32_t boxp = pack_box(box_xy, box_wh, X0, Y0);
-                        b0 += kBatch;
-                        const bool more = b0 < end;
-                        if (more) {
-                            cur_ok = nid < L.T;                 // (stale indices and the list's end: no work)
-                            if (cur_ok) {
-                                cur_t = load_tri(proj + (size_t)nid * 9);
-                                cur_id = L.orig_of ? L.orig_of[nid] : nid;
-                                // The resolve will gather the winners' colours and normals — 72 bytes each
-                                // that nobody has touched yet, straight from HBM at the end of every tile
-                                // (0.13 ms of the 10 M-triangle launch, all workgroups of a CU waiting
-                                // together).  Touch the lines now, under the sweep: they wait in the L2.
-                                if (!(dbg & (1 << 24))) {
-                                    touch0 = col[(size_t)nid * 9]; touch1 = col[(size_t)nid * 9 + 8];
-                                    touch2 = nrm[(size_t)nid * 9]; touch3 = nrm[(size_t)nid * 9 + 8];
-                                }
-                            }
-                            nid = entry_at(b0 + kBatch + (uint32_t)tid);
-                        }
-                        wave_sweep(wl, key, have, t, low, boxp, X0, Y0, lane, dbg);
-                        asm volatile("" : : "v"(touch0), "v"(touch1), "v"(touch2), "v"(touch3));
-                        if (!more) break;
-                        if (cur_ok) {
-                            int xl, xr, yt, yb;
-                            pixel_box(cur_t.x0, cur_t.y0, cur_t.x1, cur_t.y1, cur_t.x2, cur_t.y2, G.W, G.H, xl, xr, yt, yb);
-                            cur_bx = (uint32_t)xl | ((uint32_t)xr << 16);
-                            cur_by = (uint32_t)yt | ((uint32_t)yb << 16);
-                        }
-                        clip_current(box_xy, box_wh);
-                    }
-                    break;      // (the barrier behind the batch loop, then the resolve)
-                }
-            }
             if constexpr (either) {
                 if (small_by_pixel) {
                     // every record's thread works out, ONCE, what an item of its record would otherwise
@@ -2555,63 +2301,11 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             np_[0] = 1.0f; np_[1] = 1.0f; np_[2] = 1.0f;
             continue;
         }
-        uint32_t at = L.pos_of ? L.pos_of[id] : id;
-        if (dbg & (1 << 26)) at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);    // (ablation: one winner per wavefront)
-        if (dbg & (1 << 25)) {                                                           // (ablation: one array instead of three)
-            shade_and_store(proj, proj, proj, at, x, y, pix, zb, cb, nb, L.light);
-            continue;
-        }
-        shade_and_store(proj, col, nrm, at, x, y, pix, zb, cb, nb, L.light);
+        shade_and_store(proj, col, nrm, L.pos_of ? L.pos_of[id] : id, x, y, pix, zb, cb, nb, L.light);
         if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = (int32_t)id;
     }
     };
-    // WAVES: a thread's four winners first — their positions in the tile-coherent arrays are one
-    // gather each, all four in flight — then the pixels one after another
-    auto resolve_ahead = [&](auto index_tag) {
-        using I = decltype(index_tag);
-        uint32_t id[4], at[4];
-        bool in[4], won[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = tid + kThreads * j;
-            in[j] = X0 + (p & (TS - 1)) < X1 && Y0 + p / TS < Y1;
-            const uint32_t low = (uint32_t)key[p];
-            won[j] = in[j] && low != KEY_LOW_PRIOR;
-            id[j] = 0xFFFFFFFEu - low;
-            at[j] = id[j];
-        }
-        if (L.pos_of) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (won[j]) at[j] = L.pos_of[id[j]];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!in[j]) continue;
-            const int p = tid + kThreads * j;
-            const int x = X0 + (p & (TS - 1)), y = Y0 + p / TS;
-            const I pix = (I)((I)y * (I)G.W + (I)x);
-            if (won[j]) {
-                shade_and_store(proj, col, nrm, at[j], x, y, pix, zb, cb, nb, L.light);
-                if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = (int32_t)id[j];
-            } else if (CLEAR) {
-                *elem(zb, pix) = 1e6f;
-                float *cp = elem(cb, (I)(pix * 3)), *np_ = elem(nb, (I)(pix * 3));
-                cp[0] = 0.0f; cp[1] = 0.0f; cp[2] = 0.0f;
-                np_[0] = 0.0f; np_[1] = 0.0f; np_[2] = 0.0f;
-                if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = -1;
-            }
-        }
-    };
-    if constexpr (WAVES && TS == 32) {
-        if (!(dbg & (2 | (1 << 25) | (1 << 26) | (1 << 23)))) {
-            if (L.addr32) resolve_ahead(uint32_t{}); else resolve_ahead(size_t{});
-        } else {
-            if (L.addr32) resolve(uint32_t{}); else resolve(size_t{});
-        }
-    } else {
-        if (L.addr32) resolve(uint32_t{}); else resolve(size_t{});
-    }
+    if (L.addr32) resolve(uint32_t{}); else resolve(size_t{});
     CR_STAMP(3);
 #ifdef CRENDER_STAMPS
     if (g_stamps && threadIdx.x == 0) g_stamps[stamp_base + 11] = __builtin_amdgcn_s_memtime();
@@ -2627,19 +2321,16 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     }
 }
 
-// WAVES: the instantiation for frames of many small triangles (scan path, 32-pixel tiles): tiles of
-// small records go through wave_sweep, which wants 8 KB of LDS per wavefront (40 KB per workgroup,
-// four workgroups per CU, 128 VGPRs); everything else as in the plain instantiation.
-template <int TS, bool CLEAR, bool WAVES = false>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WAVES ? kWavesPerSimdWaves : TS == 16 ? kWavesPerSimd16 : TS == 32 ? kWavesPerSimd32 : 1)))
+template <int TS, bool CLEAR>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? kWavesPerSimd16 : TS == 32 ? kWavesPerSimd32 : 1)))
 void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
               const float *__restrict__ nrm, TileLists L,
               float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
               int32_t *__restrict__ win, Geom G, int dbg_arg)
 {
-    __shared__ __attribute__((aligned(16))) unsigned long long key[TS * TS];
-    __shared__ __attribute__((aligned(16))) unsigned char qraw[raster_queue_bytes<TS, WAVES>()];
-    raster_body<TS, CLEAR, WAVES>(proj, col, nrm, L, zb, cb, nb, win, G, dbg_arg, (int)blockIdx.x, key, qraw);
+    __shared__ __attribute__((aligned(16))) unsigned long long key[TS * TS];   // (the pixel owners read it as float4)
+    __shared__ __attribute__((aligned(16))) unsigned char qraw[raster_queue_bytes<TS>()];
+    raster_body<TS, CLEAR>(proj, col, nrm, L, zb, cb, nb, win, G, dbg_arg, (int)blockIdx.x, key, qraw);
 }
 
 // One launch per frame for a stream of frames (crender_pipeline_*, direct bins): the raster pass of
@@ -2667,7 +2358,7 @@ template <int TS, bool CLEAR>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? kWavesPerSimd16 : TS == 32 ? kWavesPerSimd32 : 1)))
 void k_frame(FrameArgs A)
 {
-    __shared__ __attribute__((aligned(16))) unsigned long long key[TS * TS];
+    __shared__ __attribute__((aligned(16))) unsigned long long key[TS * TS];   // (the pixel owners read it as float4)
     __shared__ __attribute__((aligned(16))) unsigned char qraw[raster_queue_bytes<TS>()];
     if ((int)blockIdx.x < A.nsetup) {
         if (threadIdx.x < kWave)
@@ -3425,20 +3116,6 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
                 hipLaunchKernelGGL((k_frame<TS, false>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, fa);
             CR_LAUNCH_CHECK("k_frame");
             plan->awaiting[par ^ 1] = false;
-            return CRENDER_OK;
-        }
-    }
-    if constexpr (TS == 32) {
-        // frames of many small triangles (scan path): the instantiation with the per-wavefront sweep
-        if (!direct && !(dbg & (1 << 28))) {
-            if (flags & CRENDER_FUSED_CLEAR)
-                hipLaunchKernelGGL((k_raster<32, true, true>), dim3(grid), dim3(kThreads), 0, s, proj, d_col, d_nrm, tl,
-                                   d_z, d_color, d_normal, d_winner, G, dbg);
-            else
-                hipLaunchKernelGGL((k_raster<32, false, true>), dim3(grid), dim3(kThreads), 0, s, proj, d_col, d_nrm, tl,
-                                   d_z, d_color, d_normal, d_winner, G, dbg);
-            CR_LAUNCH_CHECK("k_raster");
-            plan->awaiting[par ^ 1] = false;     // zeroed by this launch
             return CRENDER_OK;
         }
     }

@@ -33,6 +33,13 @@ __global__ __launch_bounds__(256) void k_rate(float *out, int trips, float seed)
             if constexpr (MODE == 8) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
             if constexpr (MODE == 9) asm volatile("v_div_fixup_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(c));
             if constexpr (MODE == 10) asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(p[i]) : "v"(c2));
+            if constexpr (MODE == 12) asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+            if constexpr (MODE == 13) asm volatile("v_mul_f32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+            if constexpr (MODE == 14) asm volatile("v_fmac_f32_e32 %0, %1, %1" : "+v"(a[i]) : "v"(c));
+            if constexpr (MODE == 15) asm volatile("v_sub_f32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+            if constexpr (MODE == 16) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+            if constexpr (MODE == 17) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c) : "vcc");
+            if constexpr (MODE == 18) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(a[i]) : "v"(c));
             if constexpr (MODE == 11) asm volatile("v_mul_f32 %0, %0, %2\n\tv_pk_mul_f32 %1, %1, %3" : "+v"(a[i]), "+v"(p[i]) : "v"(c), "v"(c2));
         }
     }
@@ -46,8 +53,8 @@ template <int MODE>
 int run(const char *name, float *out)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    const int trips = 4096;
-    for (int wps : {1, 2, 4, 8}) {
+    const int trips = 16384;
+    for (int wps : {2, 4, 8}) {
         // 256 CUs, 4 SIMDs each; a 256-thread workgroup = one wavefront per SIMD
         const int blocks = 256 * wps;
         float best = 1e9f;
@@ -68,7 +75,14 @@ int run(const char *name, float *out)
 int main()
 {
     float *out; CK(hipMalloc(&out, 4096));
-    run<0>("v_mul_f32", out);
+    run<0>("v_mul_f32 (e32)", out);
+    run<13>("v_mul_f32_e64", out);
+    run<12>("v_add_f32_e32", out);
+    run<15>("v_sub_f32_e32", out);
+    run<14>("v_fmac_f32_e32", out);
+    run<16>("v_add_u32_e32", out);
+    run<17>("v_cndmask_b32_e32", out);
+    run<18>("v_mad_u32_u24 (VOP3)", out);
     run<1>("v_pk_mul_f32", out);
     run<2>("v_fma_f32", out);
     run<3>("v_pk_fma_f32", out);
