@@ -49,6 +49,10 @@ class DeviceModel:
             raise _capi.CrenderError("DeviceModel needs a ROCm GPU")
         self.device = torch.device(device)
         self._host = model                      # parser / rotate / normals live there
+        # Counts every rewrite of the *_by_triangles arrays.  The transforms write them in place
+        # through raw pointers, which torch's version counter never sees: a filler that keeps a
+        # sorted snapshot of the arrays (tile-coherent order) compares this number instead.
+        self.generation = 0
         self._upload()
 
     # ------------------------------------------------------------------ plumbing --
@@ -102,6 +106,7 @@ class DeviceModel:
         self._gather(self._colors, idx, self._colors_by_triangles)
 
     def _gather(self, attr, index, out):
+        self.generation += 1
         with torch.cuda.device(self.device):
             _capi.check(self._lib.crender_model_gather(attr.data_ptr(), index.data_ptr(), out.data_ptr(),
                                                        index.shape[0], self._stream()), "crender_model_gather")
@@ -218,3 +223,4 @@ class DeviceModel:
         T = self.n_triangles()
         self._colors_by_triangles = torch.tensor(bgr, dtype=torch.float32, device=self.device) \
             .expand(T, 3, 3).contiguous()
+        self.generation += 1

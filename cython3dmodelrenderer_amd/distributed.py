@@ -31,6 +31,8 @@ device tensors are staged through the host.
 from __future__ import annotations
 
 import numpy as np
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -124,14 +126,27 @@ class Gatherer:
                 p[y0:y1].copy_(out[r * block: r * block + (y1 - y0)])
 
 
-_default_gatherers = {}
+# Staging of the free functions below, one Gatherer per process group for as long as the group object
+# lives (weak keys: a destroyed group's staging goes with it, and a new group that happens to get the
+# old one's address starts clean); the default group (None) has an entry of its own.  A Gatherer's
+# staging tensors carry no stream ordering of their own: use one from ONE stream at a time
+# (StripRenderer owns its Gatherer and exchanges on one communication stream).
+_default_gatherers = weakref.WeakKeyDictionary()
+_world_gatherer = []
 
 
 def _gatherer(group):
-    g = _default_gatherers.get(id(group))
-    if g is None:
-        g = _default_gatherers[id(group)] = Gatherer(group)
-    return g
+    if group is None:
+        if not _world_gatherer:
+            _world_gatherer.append(Gatherer(None))
+        return _world_gatherer[0]
+    try:
+        g = _default_gatherers.get(group)
+        if g is None:
+            g = _default_gatherers[group] = Gatherer(group)
+        return g
+    except TypeError:            # a group object that cannot be weakly referenced: no caching
+        return Gatherer(group)
 
 
 def gather_blocks(p, rank, world, block, rows_of, group=None):

@@ -368,7 +368,7 @@ class AdvancedPixelBufferFiller:
     def _win_ptr(self):
         return self.winner_buffer.data_ptr() if self.winner_buffer is not None else None
 
-    def _launch(self, flags, inputs=None, private=False):
+    def _launch(self, flags, inputs=None, private=False, generation=None):
         self._join_pipe()
         if self._unverified and not self._checking and not (flags & _capi.FUSED_CLEAR):
             # This frame composites on top of the previous one.  If that one overflowed its bin
@@ -377,7 +377,7 @@ class AdvancedPixelBufferFiller:
             # the reference's result (the later call must win equal depths).
             self._check_bins()
         if inputs is not None:
-            self._inputs, self._order = self._tile_coherent(inputs, bool(private))
+            self._inputs, self._order = self._tile_coherent(inputs, bool(private), generation)
             self._inputs_private = bool(private) or self._order is not None
         tri, col, nrm = self._inputs
         T = tri.shape[0]
@@ -402,7 +402,7 @@ class AdvancedPixelBufferFiller:
         self._host_fresh = False
         self._unverified = True
 
-    def _tile_coherent(self, inputs, private):
+    def _tile_coherent(self, inputs, private, generation=None):
         """Large models are kept in HBM in tile-coherent order: sorted, once per upload, by the
         Morton code of the screen tile each triangle's centroid projects to, so that the raster
         kernel's gathers by list entry and by winning triangle read neighbouring records instead
@@ -410,24 +410,32 @@ class AdvancedPixelBufferFiller:
         for 1.5 GB of algorithmic bytes before).  The kernels keep speaking the caller's indices
         (depth ties, winner plane) through the two index arrays returned with the sorted copies.
 
-        Who gets sorted: by default (``presort=None``) only arrays this filler OWNS — numpy inputs it
-        uploaded itself — from 2^18 triangles on.  Device tensors handed in by the caller are used in
-        place as they are (``render_frame`` then sees what the caller writes into them between
-        frames, as for small models); ``presort=True`` sorts those too, which makes the resident copy
-        a SNAPSHOT of the tensors at the time of the ``render_model`` / ``render_arrays`` call: the
-        permutation and the sorted copy are cached per (address, shape, torch version counter) of
-        the three tensors, so repeated calls on unchanged tensors cost nothing and a torch in-place
-        write (which bumps the counter) re-sorts at the next call.  Cost of one sort at 10 M
-        triangles: keys + radix sort + three gathers, about 1 GB of traffic, ~2 ms."""
+        Who gets sorted: by default (``presort=None``) arrays whose every change this filler gets to
+        know — numpy inputs it uploaded itself, and the arrays of a model that counts its own
+        changes (``DeviceModel.generation``) — from 2^18 triangles on.  Bare device tensors handed in
+        by the caller are used in place as they are (``render_frame`` then sees what the caller
+        writes into them between frames, as for small models).  ``presort=True`` sorts those too,
+        which makes the resident copy a SNAPSHOT taken at every ``render_model`` / ``render_arrays``
+        call: re-sorted each time, because nothing tells the filler whether a tensor was rewritten —
+        torch's version counter misses every write through ``data_ptr()`` (a HIP kernel, ctypes).
+        ``presort="static"`` is the caller's promise that only torch writes the tensors: the
+        permutation and the sorted copy are then cached per (address, shape, torch version counter)
+        and redone after a torch in-place write.  A generation-counting model is cached per
+        (address, shape, generation) under any policy.  Cost of one sort at 10 M triangles: keys +
+        radix sort + three gathers, about 1 GB of traffic, ~2 ms."""
         tri, col, nrm = inputs
         T = tri.shape[0]
-        want = self._presort if self._presort is not None else (private and T >= (1 << 18))
+        tracked = generation is not None
+        want = bool(self._presort) if self._presort is not None else ((private or tracked) and T >= (1 << 18))
         if not want or T < 2 or T >= (1 << 31):
             return inputs, None
         key = None
         if not private:
-            key = tuple((a.data_ptr(), tuple(a.shape), a._version) for a in inputs)
-            if self._sort_cache is not None and self._sort_cache[0] == key:
+            if tracked:
+                key = ("generation", generation) + tuple((a.data_ptr(), tuple(a.shape)) for a in inputs)
+            elif self._presort == "static":
+                key = tuple((a.data_ptr(), tuple(a.shape), a._version) for a in inputs)
+            if key is not None and self._sort_cache is not None and self._sort_cache[0] == key:
                 return self._sort_cache[1], self._sort_cache[2]
         keys = torch.empty(T, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
@@ -502,7 +510,10 @@ class AdvancedPixelBufferFiller:
         ``refresh_views=False`` (extension) leaves the numpy arrays handed out earlier stale until
         the next getter call — for callers that go on working on the device first (Renderer)."""
         src = (model._vertices_by_triangles, model._colors_by_triangles, model._normals_by_triangles)
-        key = tuple((id(a), getattr(a, "shape", None)) for a in src)
+        # a model that rewrites its arrays in place (DeviceModel: HIP kernels through raw pointers,
+        # invisible to torch's version counter) counts its changes itself
+        generation = getattr(model, "generation", None)
+        key = tuple((id(a), getattr(a, "shape", None)) for a in src) + (generation,)
         private = not any(isinstance(a, torch.Tensor) for a in src)
         if refresh or not self.cache_inputs or key != self._input_key:
             inputs = self._upload(src, ("model._vertices_by_triangles", "model._colors_by_triangles",
@@ -515,7 +526,7 @@ class AdvancedPixelBufferFiller:
             self._host_exposed = False
         else:
             self._push_host_edits()
-        self._launch(_capi.FUSED_CLEAR if clear else 0, inputs, private=private)
+        self._launch(_capi.FUSED_CLEAR if clear else 0, inputs, private=private, generation=generation)
         if self._host and refresh_views:
             # arrays handed out earlier are views of the reference's own buffers there: they show
             # this render too

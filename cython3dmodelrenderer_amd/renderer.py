@@ -4,6 +4,19 @@ illumination, return the colour buffer."""
 import numpy as np
 
 
+def _device_form_is_the_same_shading(illumination):
+    """True if the class that defines ``draw_illumination_device`` is the one that defines
+    ``draw_illumination`` (or derives from it): the device form then belongs to the host form in
+    force.  A subclass overriding only ``draw_illumination`` makes the inherited device form stale."""
+    host_at = dev_at = None
+    for i, cls in enumerate(type(illumination).__mro__):
+        if host_at is None and "draw_illumination" in vars(cls):
+            host_at = i
+        if dev_at is None and "draw_illumination_device" in vars(cls):
+            dev_at = i
+    return dev_at is not None and host_at is not None and dev_at <= host_at
+
+
 class Renderer:
     def __init__(self, pixel_buffer_filler, illumination, triangle_iterator_type=None,
                  image_height=512, image_width=512, use_tqdm=True, on_device=None):
@@ -37,6 +50,10 @@ class Renderer:
             filler.render_model(model, clear=True)
             return filler.get_color_tensor()
         device_form = getattr(self.illumination, "draw_illumination_device", None)
+        if self.on_device is None and not _device_form_is_the_same_shading(self.illumination):
+            # a subclass that overrides draw_illumination alone — the reference's only hook
+            # (renderer.py:47-49) — gets ITS shading, on the host views, not the parent's device form
+            device_form = None
         if self.on_device is not False and device_form is not None and hasattr(filler, "get_color_tensor"):
             # (the views handed out so far are refreshed by the getter below, after the shading)
             filler.render_model(model, refresh_views=False)

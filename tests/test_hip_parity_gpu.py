@@ -1392,19 +1392,73 @@ def test_presort_policy_for_caller_owned_tensors(oracle):
         filler.render_frame()
     assert_bit_equal(filler.get_z_buffer(), want[1].z_buffer, "caller-owned tensors rewritten in place")
     assert_bit_equal(filler.get_color_buffer(), want[1].color_buffer, "colour")
-    # explicit presort: snapshot + cache
+    # presort="static" (the caller promises that only torch writes the tensors): snapshot + cache
     dt.copy_(torch.from_numpy(tri))
-    snap = AdvancedPixelBufferFiller(1024, 1024, fov=45, presort=True)
+    snap = AdvancedPixelBufferFiller(1024, 1024, fov=45, presort="static")
     snap.render_arrays(dt, dc, dn, clear=True)
     first = snap._inputs
     assert snap._order is not None
     snap.render_arrays(dt, dc, dn, clear=True)
     assert snap._inputs is first, "unchanged tensors: the sorted copy is reused"
-    assert_bit_equal(snap.get_z_buffer(), want[0].z_buffer, "presort=True")
+    assert_bit_equal(snap.get_z_buffer(), want[0].z_buffer, 'presort="static"')
     dt.copy_(torch.from_numpy(tri2))           # bumps the version counter
     snap.render_arrays(dt, dc, dn, clear=True)
     assert snap._inputs is not first
-    assert_bit_equal(snap.get_z_buffer(), want[1].z_buffer, "presort=True after an in-place write")
+    assert_bit_equal(snap.get_z_buffer(), want[1].z_buffer, 'presort="static" after an in-place write')
+    # presort=True: a snapshot per call, whoever wrote the tensors — here a HIP kernel through the
+    # raw pointer, which torch's version counter does not see (the advisor's round-3 finding)
+    dt.copy_(torch.from_numpy(tri))
+    every = AdvancedPixelBufferFiller(1024, 1024, fov=45, presort=True)
+    every.render_arrays(dt, dc, dn, clear=True)
+    assert every._order is not None
+    assert_bit_equal(every.get_z_buffer(), want[0].z_buffer, "presort=True")
+    version = dt._version
+    import ctypes as C
+    from cython3dmodelrenderer_amd import _capi
+    lib = _capi.load()
+    s3 = (C.c_double * 3)(0.01, -0.02, 0.0)
+    _capi.check(lib.crender_model_shift(dt.data_ptr(), 3 * T, s3, 1,
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "crender_model_shift")
+    assert dt._version == version, "a write through data_ptr() is invisible to torch"
+    tri3 = (tri.reshape(-1, 3) + np.array([0.01, -0.02, 0.0], np.float32)).reshape(tri.shape)
+    assert np.array_equal(dt.cpu().numpy(), tri3)
+    f3 = oracle.OracleFiller(1024, 1024, fov=45)
+    f3.render_arrays(tri3, col, nrm)
+    every.render_arrays(dt, dc, dn, clear=True)
+    assert_bit_equal(every.get_z_buffer(), f3.z_buffer, "presort=True after a raw-pointer write")
+    assert_bit_equal(every.get_color_buffer(), f3.color_buffer, "colour")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("presort", [True, None])
+def test_presorted_filler_follows_a_device_model_through_its_transforms(oracle, presort):
+    """DeviceModel rewrites its *_by_triangles arrays in place with HIP kernels (no torch version
+    bump).  A filler that keeps a tile-coherent snapshot of them must notice: the model counts its
+    changes (`generation`) and the filler folds the count into its keys."""
+    from cython3dmodelrenderer_amd.data_structures import Model, DeviceModel
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    from cython3dmodelrenderer_amd.scenes import fit_model
+    rng = np.random.default_rng(4)
+    V, T = 3000, 6000
+    vertices = rng.standard_normal((V, 3)).astype(np.float32)
+    faces = rng.integers(0, V, (T, 3)).astype(np.int32)
+    host, dm = Model(vertices, faces), DeviceModel(Model(vertices, faces))
+    for m in (host, dm):
+        m.set_uniform_color()
+        fit_model(m)
+    filler = AdvancedPixelBufferFiller(512, 512, fov=45, presort=presort)
+    for step, move in enumerate((None, [0.05, 0.0, 0.1], [-0.1, 0.02, 0.0])):
+        if move is not None:
+            dm.shift(move)
+            host.shift(move)
+        filler.render_model(dm, clear=True)
+        if presort:
+            assert filler._order is not None
+        ref = oracle.OracleFiller(512, 512, fov=45)
+        ref.render_model(host)
+        assert_bit_equal(filler.get_z_buffer(), ref.z_buffer, f"step {step} z")
+        assert_bit_equal(filler.get_color_buffer(), ref.color_buffer, f"step {step} colour")
+        assert_bit_equal(filler.get_normals_buffer(), ref.normals_buffer, f"step {step} normal")
 
 
 def test_views_cross_pcie_only_when_handed_out(oracle):

@@ -325,3 +325,57 @@ def test_strip_rows_partition():
         assert rows[0][0] == 0 and rows[-1][1] == H
         assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
         assert len({y1 - y0 for y0, y1 in rows}) == 1 or H % n != 0
+
+
+def test_renderer_takes_an_overridden_illumination_not_the_inherited_device_form():
+    """The reference's only shading hook is draw_illumination (cy/renderer.py:47-49).  A subclass of
+    GuroIllumination that overrides it alone must get ITS shading in the default mode, not the
+    parent's device kernel (advisor, round 3)."""
+    from cython3dmodelrenderer_amd.illumination import GuroIllumination
+    from cython3dmodelrenderer_amd.illumination.illumination_drawer import NoIllumination
+    from cython3dmodelrenderer_amd.renderer import Renderer, _device_form_is_the_same_shading
+
+    class Half(GuroIllumination):
+        def draw_illumination(self, color_buffer, n_buffer):
+            color_buffer *= np.float32(0.5)
+
+    class Both(GuroIllumination):
+        def draw_illumination(self, color_buffer, n_buffer):
+            color_buffer *= np.float32(0.25)
+
+        def draw_illumination_device(self, filler):
+            filler.device_calls += 1
+            return True
+
+    assert _device_form_is_the_same_shading(GuroIllumination())
+    assert _device_form_is_the_same_shading(NoIllumination())
+    assert not _device_form_is_the_same_shading(Half())
+    assert _device_form_is_the_same_shading(Both())
+
+    class FakeFiller:
+        def __init__(self):
+            self.color = np.full((2, 2, 3), 8.0, np.float32)
+            self.normals = np.zeros((2, 2, 3), np.float32)
+            self.device_calls = 0
+
+        def render_model(self, model, **kw):
+            pass
+
+        def get_color_buffer(self):
+            return self.color
+
+        def get_normals_buffer(self):
+            return self.normals
+
+        def get_color_tensor(self):
+            return self.color
+
+    f = FakeFiller()
+    out = Renderer(f, Half()).render(object())
+    assert np.all(out == 4.0) and f.device_calls == 0
+    f = FakeFiller()
+    Renderer(f, Both()).render(object())
+    assert f.device_calls == 1 and np.all(f.color == 8.0)
+    f = FakeFiller()
+    Renderer(f, Both(), on_device=False).render(object())
+    assert f.device_calls == 0 and np.all(f.color == 2.0)
