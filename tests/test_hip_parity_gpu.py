@@ -1695,3 +1695,53 @@ def test_full_size_idempotence_and_strips_through_the_pixel_owners(hip, golden, 
     strips = list(zip(cuts, cuts[1:]))
     parts = gpu_frame(hip, tri, col, nrm, res, res, mode="fused", strips=strips, clear=True)
     assert (sha(parts[0]), sha(parts[1]), sha(parts[2])) == (g["z"], g["c"], g["n"]), "ragged strips"
+
+
+def _bench_line(args, nproc, timeout=600):
+    """Run bench.py as the driver does for N > 1 — a fresh child, `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` —
+    and return rank 0's one JSON line."""
+    import json, socket, subprocess, sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", str(nproc)] + args
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line from rank 0, got {len(lines)}: {out.stdout[-2000:]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_launch_contract_two_ranks_strips():
+    """The N > 1 contract of bench.py end to end, so that the first multi-GPU scaling run measures
+    RCCL and not argument parsing: two ranks on the one GPU (gloo carries the timings; --no-gather
+    because gloo cannot all-gather device strips in place), north_star's layout (row strips of
+    T-Rex 8192^2, strong scaling), the CPU baseline beside it."""
+    d = _bench_line(["--backend", "gloo", "--no-gather", "--steps", "3", "--warmup", "1"], 2)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["scaling"] == "strong" and d["config"]["workload"] == "trex8192"
+    assert d["metric"].startswith("frames") and d["unit"] == "frames/s" and d["higher_is_better"] is True
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"]
+    for key in ("ms_per_step_without_exchange", "cpu_baseline", "strong_scaling_reference", "roofline"):
+        assert key in d, key
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and "1" in cb["frames_per_s_by_threads"]
+    assert len(cb["frames_per_s_by_threads"]) >= min(4, 1 + sum(t <= cb["host_cpus"] for t in (8, 16)) + 1) - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_launch_contract_two_ranks_frames():
+    """--mode frames: every rank its own full frames, no collective in the data path (weak scaling)."""
+    d = _bench_line(["--backend", "gloo", "--mode", "frames", "--workload", "trex1024", "--steps", "5",
+                     "--warmup", "2", "--no-api-calls"], 2)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["workload"] == "trex1024"
+    assert d["value"] > 0 and "cpu_baseline" in d and "roofline" in d
