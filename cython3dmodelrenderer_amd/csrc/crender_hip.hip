@@ -2498,8 +2498,9 @@ __global__ __launch_bounds__(kThreads) void k_present_u8(const float *__restrict
 // shift / scale / mean vertex / max span / the *_by_triangles gathers, each in numpy's own float32
 // (or, where numpy promotes, float64) operation order, so that a device-resident model hands the
 // filler the very arrays the reference's Model would (tests: bit for bit against the host Model).
-// rotate and the vertex-normal computation (below) agree with numpy to 1e-5, not bit for bit: they
-// go through BLAS kernels there whose summation order is not a property of the reference.
+// rotate and the vertex-normal computation (below) go through numpy's BLAS on the host: the device
+// spells out what that BLAS computes for 3-vectors (dot3_f32) and agrees with the host Model bit for
+// bit on every mesh tested; what is NOT the reference's property is the BLAS build itself.
 __global__ __launch_bounds__(kThreads) void k_model_shift(float *__restrict__ v, size_t n, double s0, double s1,
                                                           double s2, int in_double)
 {
@@ -2608,13 +2609,16 @@ __global__ __launch_bounds__(kThreads) void k_model_rotate(float *__restrict__ v
 
 // Model._compute_normals_by_vertex (model.py:175-208), step 1: the unit normal of every face,
 // n = -cross(v1 - v0, v1 - v2) in float32 (numpy's cross: each product rounded, then the
-// difference), divided by its norm unless that is 0.  The norm is sqrt(n . n) with the three
-// products summed left to right in float32 — numpy takes it from its BLAS sdot, whose summation
-// order is a property of the build (this image's agrees with left-to-right on 78 % of random
-// vectors, with the fused and the double-precision orders on fewer): 1 ulp apart at most.
+// difference), divided by its norm unless that is 0.  The norm is np.linalg.norm = sqrt(n . n):
+// np.dot of two float32 3-vectors as numpy computes it: its BLAS (OpenBLAS sdot, kernel/x86_64/sdot.c)
+// forms the products in float32 and adds them up in a DOUBLE accumulator, rounding to float32 once at
+// the end — 200 000 random and near-parallel vector pairs agree with this spelling bit for bit, where the
+// plain float32 sum agrees on 81 % (tests/test_host_cpu.py::test_numpy_dot_of_3_vectors).  np.linalg.norm
+// of a float32 vector is the float32 square root of that dot.
 CR_DEV float dot3_f32(const float a[3], const float b[3])
 {
-    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+    const float p0 = a[0] * b[0], p1 = a[1] * b[1], p2 = a[2] * b[2];
+    return (float)(((double)p0 + (double)p1) + (double)p2);
 }
 CR_DEV void unit3_f32(float n[3])
 {

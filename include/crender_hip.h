@@ -299,11 +299,13 @@ CRENDER_API int crender_present_u8(const float *d_color, unsigned char *d_out, i
  *                         (d_offsets int32 [V + 1], d_occurrences int32 [3 T]: per vertex the faces of
  *                         its (face, corner) occurrences, ascending; d_taken: 3 T bytes of scratch).
  *                         d_faces int32 [T][3] with non-negative indices.
- * Unlike the rows above these two agree with numpy to 1e-5, not bit for bit: numpy takes
- * np.linalg.norm / np.dot / matmul from its BLAS build, whose summation order is not the
- * reference's property (plain left-to-right float32 here); the de-duplication test `dot >= 1`
- * is discontinuous, so a 1-ulp difference can change which face normals a vertex averages
- * (counted and bounded in tests/test_hip_parity_gpu.py::test_device_model_rotate_and_normals). */
+ * numpy takes np.linalg.norm / np.dot / matmul from its BLAS build.  For the 3-vectors of this path
+ * that is: float32 products added in a double accumulator and rounded once (OpenBLAS sdot), a
+ * three-term float64 sum for the rotation — spelled out as such in the kernels, and bit-identical
+ * to the host Model on every mesh of tests/test_hip_parity_gpu.py::test_device_model_rotate_and_normals
+ * (the de-duplication test `dot >= 1` is discontinuous: a 1-ulp difference in the dot would change
+ * which face normals a vertex averages, as rounds 1-3's plain float32 sum did on 0.8 % of T-Rex's
+ * vertices). */
 CRENDER_API int crender_model_rotate(float *d_vertices, int64_t V, const double *R9, void *stream);
 CRENDER_API int crender_model_vertex_normals(const float *d_vertices, int64_t V, const int32_t *d_faces, int64_t T,
                                              const int32_t *d_offsets, const int32_t *d_occurrences,

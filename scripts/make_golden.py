@@ -107,6 +107,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     # ---- inputs ------------------------------------------------------------------
     trex = Model.read_model(os.path.join(REF, "objects", "T-Rex.obj"))
+    # the mesh as parsed, before any transform: what a device-resident Model starts from (the test
+    # that takes it through rotate x 2 + fit on the GPU must arrive at trex_inputs.npz, bit for bit)
+    np.savez_compressed(os.path.join(OUT, "trex_mesh.npz"), vertices=trex._vertices.astype(np.float32),
+                        faces=np.asarray(trex._triangles_vertices, dtype=np.int32))
+    if "--only-trex-mesh" in sys.argv:
+        return
     trex.rotate([-90, 180, 0])
     trex.rotate([10, -80, 0])
     fit_model(trex)

@@ -379,3 +379,24 @@ def test_renderer_takes_an_overridden_illumination_not_the_inherited_device_form
     f = FakeFiller()
     Renderer(f, Both(), on_device=False).render(object())
     assert f.device_calls == 0 and np.all(f.color == 2.0)
+
+
+def test_numpy_dot_of_3_vectors():
+    """What the device's vertex-normal kernels assume of numpy (row f2): np.dot of two float32
+    3-vectors — and np.linalg.norm through it — forms float32 products and adds them in a double
+    accumulator, rounding once (OpenBLAS sdot).  If a numpy build ever differs, this fails before
+    the GPU tests do."""
+    rng = np.random.default_rng(0)
+    n = 20000
+    a = rng.standard_normal((n, 3)).astype(np.float32)
+    b = rng.standard_normal((n, 3)).astype(np.float32)
+    a[: n // 2] /= np.linalg.norm(a[: n // 2], axis=1, keepdims=True)
+    b[: n // 2] = a[: n // 2] + rng.standard_normal((n // 2, 3)).astype(np.float32) * np.float32(1e-4)
+    ref = np.array([np.dot(a[i], b[i]) for i in range(n)], dtype=np.float32)
+    p = a * b
+    mine = (p[:, 0].astype(np.float64) + p[:, 1].astype(np.float64) + p[:, 2].astype(np.float64)).astype(np.float32)
+    assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
+    norms = np.array([np.linalg.norm(a[i]) for i in range(2000)], dtype=np.float32)
+    sq = a[:2000] * a[:2000]
+    mine = np.sqrt((sq[:, 0].astype(np.float64) + sq[:, 1].astype(np.float64) + sq[:, 2].astype(np.float64)).astype(np.float32))
+    assert np.array_equal(mine.view(np.uint32), norms.view(np.uint32))
