@@ -235,8 +235,7 @@ def main():
     ap.add_argument("--synth-triangles", type=int, default=10_000_000)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--pipeline-tile", type=int, default=0,
-                    help="tile size of the swap chain's plans when it should differ from --tile (throughput "
-                         "against single-frame latency: DESIGN.md section 6)")
+                    help="A/B knob: tile size of the swap chain's plans (default: the chain's own choice, 32)")
     ap.add_argument("--max-triangles", type=int, default=-1,
                     help="experiment knob: keep only the first N triangles (0 = pure clear)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -317,8 +316,11 @@ def main():
         sr = None
         filler = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile,
                                            pipeline=not args.no_pipeline,
-                                           pipeline_depth=args.pipeline_depth, pipeline_tile=args.pipeline_tile,
+                                           pipeline_depth=args.pipeline_depth,
                                            lookahead={"auto": None, "on": True, "off": False}[args.lookahead])
+
+    if args.pipeline_tile:
+        filler._pipeline_tile = args.pipeline_tile       # (A/B knob: the chain's own choice otherwise)
 
     def step(pipelined=True, gather=True):
         if sr is not None:
@@ -400,7 +402,7 @@ def main():
     lookahead = filler._pipe is not None and filler._pipe.lookahead
     kframe_events_ms = kframe_b2b_ms = None
     if lookahead:
-        probe = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.pipeline_tile or args.tile, pipeline=True,
+        probe = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=filler._pipe.tile, pipeline=True,
                                           pipeline_depth=1, lookahead=True,
                                           row_strip=(y0, y1) if strips else None)
         probe.render_arrays(tri, col, nrm, clear=True)
@@ -473,7 +475,7 @@ def main():
         # The roofline uses the LONGER of the two, i.e. never the flattering one.
         single_ms = elapsed_single / args.steps * 1e3
         raster_b2b_ms = max(single_ms - bin_ms, 0.0)
-        ts = (args.pipeline_tile if lookahead and args.pipeline_tile else filler.tile) or (16 if H * W <= 1024 * 1024 else 32)
+        ts = (filler._pipe.tile if lookahead else filler.tile) or (16 if H * W <= 1024 * 1024 else 32)
         if lookahead:
             kernel = f"k_frame<{ts},true>"
             views = {"hip_events_around_each_launch": kframe_events_ms, "frames_back_to_back_on_one_stream": kframe_b2b_ms}
@@ -507,7 +509,8 @@ def main():
                                      f"all-gather, exchange = {args.exchange}, {args.chunks} sub-strip(s) per rank, "
                                      f"projection = {'rank 0, broadcast of the projected vertices' if args.project == 'broadcast' else 'every rank its own (model replicated)'}"
                                      if strips else "independent full frames per rank, no collective"),
-                       "tile": filler.tile or "auto", "pipeline_tile": args.pipeline_tile or "same",
+                       "tile": filler.tile or "auto",
+                       "pipeline_tile": filler._pipe.tile if filler._pipe is not None else None,
                        "frame": "clear + project + rasterize, model resident in HBM",
                        "pipelined": (False if args.no_pipeline else
                                      f"swap chain of {filler._pipeline_depth} (GPU_MAX_HW_QUEUES="

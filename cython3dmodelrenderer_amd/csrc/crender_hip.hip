@@ -407,11 +407,18 @@ constexpr int kEntryPieces = sizeof(BinEntry) / 16;
 // readers, the counter of the NEXT frame by k_raster.
 constexpr uint32_t kHeavyAt = 32;     // lists from here on are split in two halves (16 x 8 pixels),
 constexpr uint32_t kQuadAt = 64;      // from here on in four quadrants (8 x 8)
+// 32-pixel tiles of a small frame rendered ALONE (the swap chain's plans at depth 1): every covered
+// tile goes to four workgroups, one per 16 x 16 quadrant — T-Rex 1024^2 has 312 covered 32-pixel
+// tiles, 99 of them with 32 records or more: split by list length the launch keeps two workgroups
+// per CU busy and takes 22 us; the 16-pixel plan's launch takes 17.
+constexpr uint32_t heavy_at(int ts) { return ts == 32 ? 1u : kHeavyAt; }
+constexpr uint32_t quad_at(int ts) { return ts == 32 ? 1u : kQuadAt; }
 struct HeavyReg {
     uint32_t *ctr = nullptr;     // this frame's counter; null = no splitting
     uint32_t *flag = nullptr;    // [ntiles]
     uint32_t *slots = nullptr;   // [3 * hmax]
     uint32_t hmax = 0;
+    uint32_t heavy_at = kHeavyAt;   // the append that makes a list this long registers the tile
     // dispatch-order hint (build_order): tiles the raster launch will clear in groups without
     // looking at their lists.  The first entry that lands in such a tile declares the hint stale.
     const unsigned char *grouped = nullptr;   // [ntiles], null = the launch is not ordered
@@ -481,7 +488,7 @@ CR_DEV void bin_direct_append(uint2 r_keep, const float4 *img, int ntx,
                     if (on[k]) {
                         if (slot[k] < dcap) put_entry<NP>(entry_at(tile[k], slot[k]), img, lane);
                         else atomicMax(&hdr[1], slot[k] + 1);
-                        if (hv.ctr && slot[k] == kHeavyAt - 1) register_heavy(hv, tile[k]);
+                        if (hv.ctr && slot[k] == hv.heavy_at - 1) register_heavy(hv, tile[k]);
                         if (slot[k] == 0) first_entry_of(hv, tile[k]);
                     }
                 }
@@ -536,7 +543,7 @@ CR_DEV void bin_direct_append(uint2 r_keep, const float4 *img, int ntx,
                     const uint32_t tile = tw[u] & 0xFFFFFu;
                     if (slot[u] < dcap) put_entry<NP>(entry_at(tile, slot[u]), img, (int)((tw[u] >> 20) & 63u));
                     else atomicMax(&hdr[1], slot[u] + 1);
-                    if (hv.ctr && slot[u] == kHeavyAt - 1) register_heavy(hv, tile);
+                    if (hv.ctr && slot[u] == hv.heavy_at - 1) register_heavy(hv, tile);
                     if (slot[u] == 0) first_entry_of(hv, tile);
                 }
             }
@@ -682,7 +689,7 @@ CR_DEV void setup_wave_body(const float *__restrict__ tri_in, const float *__res
                 if (c[k]) {
                     hist[(k0 + k) * kWave + lane] = base[k];
                     if (base[k] + c[k] > dcap) atomicMax(&hdr[1], base[k] + c[k]);
-                    if (hv.ctr && base[k] < kHeavyAt && base[k] + c[k] >= kHeavyAt) register_heavy(hv, t[k]);
+                    if (hv.ctr && base[k] < hv.heavy_at && base[k] + c[k] >= hv.heavy_at) register_heavy(hv, t[k]);
                     if (base[k] == 0) first_entry_of(hv, t[k]);
                 }
             }
@@ -1439,11 +1446,12 @@ CR_DEV bool load_record(const TileLists &L, const float *__restrict__ proj, cons
 // if it is not empty after all — so a stale order (another model, a first frame) costs time,
 // never pixels.  Built by the launch's first workgroup from this frame's counters, which no
 // workgroup writes; read by the next launch (ping-pong buffers).
-constexpr int kGroup = 8;      // empty tiles cleared per workgroup of the order's last section
+constexpr int kGroup = 8;      // empty 16-pixel tiles cleared per workgroup of the order's last section
+constexpr int group_tiles(int ts) { return ts >= 32 ? kGroup / 4 : kGroup; }   // (the same 56 KB of 32-pixel tiles)
 constexpr int kOrderMaxTiles = 8192;   // the builder keeps one byte per tile in the 13 KB of the batch queue
 CR_DEV void build_order(const uint32_t *__restrict__ count, int ntx, int nty,
                         uint32_t *__restrict__ order_next, unsigned char *__restrict__ grouped_next,
-                        uint32_t *__restrict__ hint_next, uint32_t *scr)
+                        uint32_t *__restrict__ hint_next, uint32_t *scr, int group)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = ntx * nty;
@@ -1507,7 +1515,7 @@ CR_DEV void build_order(const uint32_t *__restrict__ count, int ntx, int nty,
     if (tid == 0) {
         const uint32_t ncov = tot[0] + tot[1] + tot[2];
         hint_next[1] = ncov + tot[3];                       // tiles with a workgroup of their own
-        hint_next[2] = (tot[4] + kGroup - 1) / kGroup;      // workgroups that clear kGroup tiles each
+        hint_next[2] = (tot[4] + group - 1) / group;        // workgroups that clear `group` tiles each
         hint_next[0] = ncov ? 1u : 0u;     // an empty frame says nothing about the next one
     }
 }
@@ -1698,7 +1706,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     // grid = [order builder, if ordered][3 * hmax helpers][ntiles main workgroups, one tile each]
     if (L.order_next) {
         if (b == 0) {
-            build_order(L.count, G.ntx, G.nty, L.order_next, L.grouped_next, L.hint_next, reinterpret_cast<uint32_t *>(qraw));
+            build_order(L.count, G.ntx, G.nty, L.order_next, L.grouped_next, L.hint_next, reinterpret_cast<uint32_t *>(qraw), group_tiles(TS));
             return;
         }
         b -= 1;
@@ -1727,13 +1735,14 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                 // float4 stores per thread and tile (no list to look at: the binning pass vouches
                 // for their emptiness, see first_entry_of)
                 if (m >= ns + ng) return;
-                const int first = ns + (m - ns) * kGroup;
-                const int ntl = G.ntiles - first < kGroup ? G.ntiles - first : kGroup;
-                uint32_t tl[kGroup];
+                constexpr int kG = group_tiles(TS);
+                const int first = ns + (m - ns) * kG;
+                const int ntl = G.ntiles - first < kG ? G.ntiles - first : kG;
+                uint32_t tl[kG];
 #pragma unroll
-                for (int j = 0; j < kGroup; ++j) tl[j] = j < ntl ? L.order[first + j] : 0u;
+                for (int j = 0; j < kG; ++j) tl[j] = j < ntl ? L.order[first + j] : 0u;
 #pragma unroll
-                for (int j = 0; j < kGroup; ++j) {
+                for (int j = 0; j < kG; ++j) {
                     if (j >= ntl) break;
                     const uint32_t tu = tl[j];
                     const int gy = G.ntx_magic ? (int)__umulhi(tu, G.ntx_magic) : (int)tu / G.ntx;
@@ -1812,7 +1821,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     int rw = TS;                 // width of this workgroup's rectangle in the key plane's terms
     if (quad >= 0) {
         constexpr int HS = TS / 2;
-        if (end - beg >= kQuadAt) {             // four quadrants
+        if (end - beg >= quad_at(TS)) {         // four quadrants
             X0 += (quad & 1) * HS; Y0 += (quad >> 1) * HS;
             if (X1 > X0 + HS) X1 = X0 + HS;
             rw = HS;
@@ -2757,6 +2766,7 @@ struct Layout {
     size_t off_hdr, off_count, off_hflag, off_hslots, off_hint, off_order, off_grouped, off_offs,
            off_trange, off_proj, off_entries, off_direct, total;
 };
+constexpr int kMaxHeavyHelped32 = 512;
 constexpr int kMaxHeavyHelped = 128;   // +384 workgroups per raster launch (9 % at 1024 x 1024)
 
 // Direct bins are for small scenes (the README benchmark): one launch fewer than the
@@ -2794,9 +2804,15 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
         L.direct_cap = kDirectBinBytes / (int64_t)sizeof(BinEntry) / L.g.ntiles;
         if (L.direct_cap > 1024) L.direct_cap = 1024;
     }
-    // heavy tiles are split on 16-pixel tiles with direct bins only (the small-frame regime,
-    // where a single tile's latency sets the end of the launch)
-    L.hmax = (L.ts == 16 && L.direct_cap >= 2 * kHeavyAt) ? (L.g.ntiles / 8 < kMaxHeavyHelped ? L.g.ntiles / 8 : kMaxHeavyHelped) : 0;
+    // heavy tiles are split with direct bins only (the small-frame regime, where a single tile's
+    // latency sets the end of the launch): on 16-pixel tiles and — for frames rendered alone on the
+    // swap chain's 32-pixel plans, whose 300 covered workgroups would leave most of 256 CUs idle — on
+    // 32-pixel tiles of small frames, where most covered tiles are heavy
+    L.hmax = 0;
+    if (L.direct_cap >= 2 * (int64_t)kHeavyAt) {
+        if (L.ts == 16) L.hmax = L.g.ntiles / 8 < kMaxHeavyHelped ? L.g.ntiles / 8 : kMaxHeavyHelped;
+        else if (L.ts == 32 && L.g.ntiles <= 2048) L.hmax = L.g.ntiles / 2 < kMaxHeavyHelped32 ? L.g.ntiles / 2 : kMaxHeavyHelped32;
+    }
     size_t o = 0;
     // [header | counters, parity 0 and 1 | heavy flags | heavy slots | order hints] are zeroed at creation
     L.off_hdr = o;     o = align_up(o + 64);
@@ -2805,7 +2821,7 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
     L.off_hflag = o;   o = align_up(o + sizeof(uint32_t) * (size_t)L.g.ntiles);
     L.off_hslots = o;  o = align_up(o + sizeof(uint32_t) * 3 * (size_t)(L.hmax > 0 ? L.hmax : 1));
     // small frames are dispatched in the order the previous frame suggests (build_order)
-    L.ordered = L.ts == 16 && L.direct_cap > 0 && L.g.ntiles <= kOrderMaxTiles;
+    L.ordered = (L.ts == 16 || (L.ts == 32 && L.g.ntiles <= 2048)) && L.direct_cap > 0 && L.g.ntiles <= kOrderMaxTiles;
     L.off_hint = o;    o = align_up(o + sizeof(uint32_t) * 8);                      // two headers of 4 words
     L.off_order = o;   o = align_up(o + sizeof(uint32_t) * 2 * (size_t)(L.ordered ? L.g.ntiles : 0));
     L.off_grouped = o; o = align_up(o + 2 * (size_t)(L.ordered ? L.g.ntiles : 0));
@@ -2977,6 +2993,7 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
         if (L.hmax > 0 && plan->frame_lone && !(dbg & 2048)) {
             hv.ctr = plan->hdr() + 2 + par; hv.flag = plan->hflag(); hv.slots = plan->hslots();
             hv.hmax = (uint32_t)L.hmax;
+            hv.heavy_at = heavy_at(TS);
         }
         if (L.ordered) {
             hv.grouped = plan->grouped(plan->hint_par);    // of the order this frame's raster pass reads

@@ -110,7 +110,7 @@ class _FramePipeline:
             if filler._lookahead is None else bool(filler._lookahead)
         for _ in range(self.depth * (2 if self.lookahead else 1)):
             cap = max(filler._bin_request, filler._bin_floor)
-            tile = filler._pipeline_tile or filler.tile
+            tile = self.tile = filler._chain_tile()
             nbytes = self.lib.crender_plan_workspace_bytes(filler.h, filler.w, filler.y0, filler.y1,
                                                            max(int(T), 1), cap, tile)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -170,9 +170,11 @@ class _FramePipeline:
                 for plan in self.plans:
                     _capi.check(self.lib.crender_plan_set_light(plan, (C.c_float * 3)(*filler._fused_light)),
                                 "crender_plan_set_light")
+            # (a chain of depth 1 runs its frames one after another: lone frames, dispatched as such)
+            overlapped = _capi.OVERLAPPED_FRAMES if self.depth > 1 else 0
             for k, (z, c, n, w) in enumerate(self.sets):
                 filler._ext.pipeline_bind(self.handle.value, k, tri, col, nrm, filler._P_t, z, c, n, w,
-                                          _capi.FUSED_CLEAR | _capi.OVERLAPPED_FRAMES | guro | want[1])
+                                          _capi.FUSED_CLEAR | overlapped | guro | want[1])
             self._args = want
         if _current_device() == self._index:
             self._submit(self._handle_int, self._index)
@@ -222,7 +224,7 @@ class AdvancedPixelBufferFiller:
     def __init__(self, h, w, fov=90.0, z_near=0.1, z_far=1000.0, n_threads=1, *,
                  device=None, tile=0, row_strip=None, track_winner=False, cache_inputs=False,
                  bin_capacity=0, direct_bins=True, pipeline=False, pipeline_depth=None,
-                 presort=None, lookahead=None, pipeline_tile=0):
+                 presort=None, lookahead=None):
         self._lib = _capi.load()                      # raises if the HIP library is missing
         self._ext = _torch_ext.load()                 # raises if the torch extension is not built
         if not torch.cuda.is_available():
@@ -276,11 +278,11 @@ class AdvancedPixelBufferFiller:
         # swap chain: the launch that rasterizes a frame also bins the slot's next frame into a second
         # plan (crender_pipeline_set_lookahead).  None = for scenes that fit the direct bins.
         self._lookahead = lookahead
-        # Tile size of the swap chain's plans when it differs from the single-frame plan's (0 = the
-        # same).  Measured on T-Rex 1024 x 1024: 32-pixel tiles carry 9 % more frames per second through
-        # the chain than 16-pixel ones (a quarter of the workgroups) while one frame alone takes 29 us
-        # instead of 17 — throughput against latency, the caller's choice.
-        self._pipeline_tile = int(pipeline_tile)
+        # Tile size of the swap chain's plans; None = the chain's own choice (_chain_tile): with `tile`
+        # left to the library, frames of a stream run on 32-pixel tiles whatever the frame size —
+        # T-Rex 1024 x 1024: 9 % more frames per second than on the 16-pixel tiles a frame rendered
+        # alone gets (a quarter of the workgroups).  (bench.py's A/B sets it.)
+        self._pipeline_tile = None
         self._order = None             # (orig_of, pos_of) int32 device tensors of the resident inputs
         self._plan_order = None        # what the single-stream plan currently holds
         self._fused_light = None       # (l0, l1, l2): illumination fused into cleared frames
@@ -347,6 +349,16 @@ class AdvancedPixelBufferFiller:
         _capi.check(self._lib.crender_plan_last_bin_usage(plan, self._stream(), C.byref(need),
                                                           C.byref(cap)), "crender_plan_last_bin_usage")
         self._plan_capacity = cap.value
+
+    def _chain_tile(self):
+        """Tile size of the swap chain's plans: the caller's `tile` if one was given; else 32-pixel
+        tiles (the library's own choice above 1024 x 1024, and the faster one for a STREAM of smaller
+        frames too), 16 for frames too small to fill the chip with them."""
+        if self._pipeline_tile is not None:
+            return int(self._pipeline_tile)
+        if self.tile:
+            return self.tile
+        return 32 if self.h * self.w >= 512 * 512 else 16
 
     def _join_pipe(self):
         """Pipelined frames run on the pipeline's streams: make the current stream wait for them
