@@ -1,7 +1,8 @@
-"""Compiles csrc/crender_hip.hip into the in-tree shared library with hipcc.
+"""Compiles csrc/*.hip into the in-tree shared library with hipcc.
 
 The library is plain HIP behind a C ABI (include/crender_hip.h): no torch headers, so
-a bare ``hipcc -shared`` is the whole build.  gfx950 only.
+``hipcc -c`` per translation unit (in parallel) and one ``hipcc -shared`` are the whole build.
+gfx950 only.
 """
 from __future__ import annotations
 
@@ -12,8 +13,10 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libcrender_hip.so")
-SOURCES = ["crender_hip.hip"]
-HEADERS = ["raster_math.h", os.path.join("..", "..", "include", "crender_hip.h")]
+# binning.hip  K1 + the binning passes      raster.hip  K2 (tile rasterizer, k_frame, atomic path)
+# model_ops.hip  rows f1-f4 of SURVEY 8f     abi.hip  plans, frames, swap chain (no kernels)
+SOURCES = ["abi.hip", "binning.hip", "raster.hip", "model_ops.hip"]
+HEADERS = ["common.h", "binning.h", "plan.h", "raster_math.h", os.path.join("..", "..", "include", "crender_hip.h")]
 
 # Float parity with the reference depends on these (DESIGN.md "Numerics"):
 #   -ffp-contract=off                           no FMA contraction (hipcc defaults to fast)
@@ -30,9 +33,9 @@ HIPCC_FLAGS = [
     "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-fno-gpu-flush-denormals-to-zero",
     "-fno-slp-vectorize",
-    "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra",
-    "-Wl,-soname,libcrender_hip.so",
+    "-fPIC", "-fvisibility=hidden", "-Wall", "-Wextra",
 ]
+LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-soname,libcrender_hip.so"]
 
 
 def _hipcc():
@@ -50,15 +53,38 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > built for d in deps)
 
 
+def compile_library(out: str, extra_flags=(), sources=None, src_dir: str = SRC_DIR, verbose: bool = False,
+                    quiet: bool = False) -> str:
+    """hipcc -c every translation unit (side by side), then link them into `out`.  `extra_flags`:
+    defines of development / diagnostic builds (-DCRENDER_DEV_KNOBS, -DCRENDER_STAMPS, ...)."""
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    sources = list(sources or SOURCES)
+    err = subprocess.DEVNULL if quiet else None
+    with tempfile.TemporaryDirectory(prefix="crender_build_") as tmp:
+        objs = [os.path.join(tmp, os.path.splitext(s)[0] + ".o") for s in sources]
+
+        def one(job):
+            src, obj = job
+            cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-c", "-o", obj, os.path.join(src_dir, src)]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, stderr=err)
+
+        with ThreadPoolExecutor(max_workers=min(4, len(sources))) as pool:
+            list(pool.map(one, zip(sources, objs)))
+        cmd = [_hipcc()] + LINK_FLAGS + ["-o", out] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, stderr=err)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Build libcrender_hip.so if missing or stale; returns its path."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(SRC_DIR, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB_PATH
+    return compile_library(LIB_PATH, verbose=verbose)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,1614 @@
+// raster.hip — K2 on gfx950 (MI355X / CDNA4): the tile rasterizer, the swap chain's one-launch frame
+// kernel and the independent global-atomic implementation; their host side.
+//
+// Frame = K1 (projection) + K2 (rasterization) of the reference's
+// AdvancedPixelBufferFiller.render_model (.pyx:92-244), restructured for the GPU:
+//
+//   k_setup   one thread per triangle: [project,] back-face cull, pixel box, tile range, and
+//             the binning.  Scenes of up to 65536 triangles append their indices straight
+//             into fixed-capacity per-tile lists ("direct bins": the frame is two launches);
+//             larger scenes count list lengths here and go through
+//   k_scan    one workgroup: exclusive scan of the tile list lengths, and
+//   k_fill    writes triangle indices into the scanned lists (block-private LDS cursors,
+//             one global atomic per (block, touched tile) to reserve list space).
+//   k_raster  one workgroup per screen tile: a 64-bit (z, index) key per pixel lives in
+//             LDS; the tile's list is swept in 4x4-pixel blocks, flattened and split evenly
+//             over sixteen 16-lane groups, with LDS atomic-min; then every pixel recomputes
+//             its winning fragment and stores z / colour / normal once (the clear is fused).
+//
+// No HBM atomics on the framebuffer and every framebuffer byte is written once per frame.
+// Build flags (see _build.py): -ffp-contract=off, correctly rounded division, denormals on —
+// float parity with the reference depends on them.
+//
+// Measurement knobs exist only in a development build (-DCRENDER_DEV_KNOBS, scripts/dev_build.sh):
+// there CRENDER_DEBUG (environment, read once) is a bit mask; the product library is compiled
+// without them (every `dbg & bit` below folds to 0):
+//   1 no coverage work, 2 no shading (both produce WRONG images: ablation timing only),
+//   4 block-histogram count / fill passes on every scan-path frame, 8 XCD-banded tile map, 16 never use direct bins, 32 no sign rejection, 64 no hoisted
+//   reciprocal, 128 small-record block sweep for every batch (64-pixel tiles), 256 invert the
+//   scatter-dispatch rule, 512 no row rotation of the tile map, 4096 coarse pass keeps every
+//   block, 8192 large-record sweep for every batch (32/64-pixel tiles), bits 16..23 = n + 1:
+//   pixel-parallel path of 16-pixel tiles for batches <= n records (n = 0 disables it; default
+//   kPixelPathRecords), 16384 frames of a swap chain are treated as lone frames (ordered dispatch
+//   and split tiles although they overlap), 32768 no pixel-owner sweep on 32-pixel tiles.
+#include "plan.h"
+
+using namespace crender_detail;
+
+namespace {
+
+// ---- tile rasterizer --------------------------------------------------------------
+// Alternative block -> tile map (debug knob 8): one contiguous band of tiles per XCD.
+// Measured SLOWER than the identity map on every workload (r01: T-Rex 8192^2 0.60 vs 0.42 ms):
+// the covered tiles cluster, so banding piles the work onto a few XCDs.  The identity map
+// deals neighbouring tiles round-robin over the XCDs and is the default.
+CR_DEV int xcd_band_tile(int b, int n)
+{
+    const int per = n >> 3, rem = n & 7;
+    const int xcd = b & 7, k = b >> 3;
+    return xcd * per + (xcd < rem ? xcd : rem) + k;
+}
+
+// Lower an LDS depth key (order-independent: the final key is the minimum over all fragments).
+CR_DEV void lds_key_min(unsigned long long *slot, unsigned long long k)
+{
+    // No pre-read of the key: a non-returning ds_min_u64 does not stall the wavefront, whereas
+    // "load, compare, then maybe atomic" puts two dependent LDS round trips on every trip's
+    // critical path (T-Rex 1024^2 raster 24.2 -> 23.6 us).
+    __hip_atomic_fetch_min(slot, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// One batch of (tile, triangle) work in LDS, struct-of-arrays, slot = thread index.
+// A record's pixel box (clipped to the tile) is cut into work items numbered row-major:
+// 4x4-pixel blocks on 32/64-pixel tiles, single pixels on 16-pixel tiles; blk_scan holds the
+// wave-local exclusive prefix of the item counts.
+struct WorkQueue {
+    float x0[kThreads], y0[kThreads], z0[kThreads];
+    float x1[kThreads], y1[kThreads], z1[kThreads];
+    float x2[kThreads], y2[kThreads], z2[kThreads];
+    uint32_t tri[kThreads];
+    // the record's pixel box clipped to the tile, TILE-LOCAL and packed: x0 | y0 << 6 | w << 12 |
+    // h << 19 (w = 0: no work).  One word instead of two: with the small-record batches' private
+    // arrays below the 32-pixel kernel stays at six workgroups per CU (27 136 bytes of LDS each).
+    uint32_t box[kThreads];
+    uint32_t wave_blocks[kThreads / 64];
+    // a batch is swept one way or the other: the two sweeps' private arrays share their memory
+    union {
+        struct {
+            unsigned long long mask[kThreads];  // large-record batches: blocks that survive the cull
+            uint32_t blk_scan[kThreads];        // exclusive prefix of the records' block counts within the wavefront
+        } big;
+        struct {                            // small-record batches of 32-pixel tiles: what depends on the
+            float l03[kThreads], l13[kThreads], l23[kThreads];   // triangle alone and is not one operation
+            float r1[kThreads], r2[kThreads], r3[kThreads];      // away — the denominators of mu.pyx:11-21 and
+            uint32_t px_scan[kThreads];                          // their refined reciprocals (r1 = 0: none);
+        } pre;                                                   // exclusive prefix of the records' item counts
+    };
+    // 32-pixel tiles count a batch both ways (blocks above, pixels in pre.px_scan) and pick the sweep after
+    uint32_t wave_px[kThreads / 64];
+};
+
+// 16-pixel tiles keep a batch's records array-of-structures with everything that depends on the
+// triangle alone worked out ONCE by the record's thread: the nine edge constants of mu.pyx:11-21
+// and the refined reciprocals of the three denominators (raster_math.h (2)).  A sample then costs
+// six 16-byte LDS reads and ~100 vector instructions instead of twelve 4-byte reads and ~140
+// (T-Rex 1024^2's raster launch is bound by the vector pipes: 3.6 M instructions x 4 cycles over
+// 1024 SIMDs).  96 bytes per record, 128 records per batch (12 KB: eight workgroups per CU).
+struct __attribute__((aligned(16))) Rec16 {
+    float x0, y0, x1, y1;
+    float x2, y2, z0, z1;
+    float z2; uint32_t low, box_xy, box_wh;      // low word of the record's depth keys; box_wh bit 31:
+                                                 // denominators inside the division window
+    float l01, l02, l11, l12;
+    float l21, l22, l03, l13;
+    float l23, r1, r2, r3;
+};
+static_assert(sizeof(Rec16) == 96, "six 16-byte pieces");
+constexpr int kBatch16 = 128;
+constexpr uint32_t kRecFast = 0x80000000u;
+
+CR_DEV void put_rec16(Rec16 *dst, const TriXYZ &t, uint32_t low, uint32_t box_xy, uint32_t box_wh)
+{
+    const TriSetup s = make_setup(t, true);
+    float4 *d = reinterpret_cast<float4 *>(dst);
+    d[0] = make_float4(t.x0, t.y0, t.x1, t.y1);
+    d[1] = make_float4(t.x2, t.y2, t.z0, t.z1);
+    d[2] = make_float4(t.z2, __uint_as_float(low), __uint_as_float(box_xy),
+                       __uint_as_float(box_wh | (s.fast ? kRecFast : 0u)));
+    d[3] = make_float4(s.l01, s.l02, s.l11, s.l12);
+    d[4] = make_float4(s.l21, s.l22, s.l03, s.l13);
+    d[5] = make_float4(s.l23, s.r1, s.r2, s.r3);
+}
+
+// A record's sample at pixel (X, Y): same operations as fragment() — the numerators of mu.pyx:34
+// from the stored edge constants, then the three correctly rounded quotients.
+struct Rec16Regs {
+    float4 a, b, c, d, e, f;
+};
+CR_DEV Rec16Regs load_rec16(const Rec16 *r)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(r);
+    return Rec16Regs{p[0], p[1], p[2], p[3], p[4], p[5]};
+}
+CR_DEV bool fragment16(const Rec16Regs &R, int X, int Y, unsigned long long &key)
+{
+    TriSetup s;
+    s.x0 = R.a.x; s.y0 = R.a.y; s.x1 = R.a.z; s.y1 = R.a.w;
+    s.x2 = R.b.x; s.y2 = R.b.y; s.z0 = R.b.z; s.z1 = R.b.w;
+    s.z2 = R.c.x;
+    s.l01 = R.d.x; s.l02 = R.d.y; s.l11 = R.d.z; s.l12 = R.d.w;
+    s.l21 = R.e.x; s.l22 = R.e.y; s.l03 = R.e.z; s.l13 = R.e.w;
+    s.l23 = R.f.x; s.r1 = R.f.y; s.r2 = R.f.z; s.r3 = R.f.w;
+    s.rej1 = s.rej2 = s.rej3 = 0.0f;
+    s.fast = (__float_as_uint(R.c.w) & kRecFast) != 0;
+    float n1, n2, n3;
+    numerators(s, X, Y, n1, n2, n3);
+    float b1, b2, b3;
+    quotients(s, n1, n2, n3, true, b1, b2, b3);
+    if (b1 < 0.0f || b2 < 0.0f || b3 < 0.0f) return false;     // .pyx:215-216 (NaN passes)
+    const float z = interp(s.z0, s.z1, s.z2, b1, b2, b3);
+    if (z != z) return false;                                  // .pyx:220
+    key = make_key(zord(z), __float_as_uint(R.c.y));
+    return true;
+}
+
+// The winner's z, colour and normal with the barycentrics taken from its LDS record (edge
+// constants and reciprocals are there already) and colour / normal gathered by triangle index:
+// the operations of shade_and_store on the same inputs (.pyx:219, 226-242), without its gather
+// of the projected vertices and its nine edge constants.
+template <typename I>
+CR_DEV void shade16_store(const Rec16Regs &R, const float *__restrict__ col, const float *__restrict__ nrm,
+                          uint32_t tri, int X, int Y, I pix,
+                          float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb, const Light &Lt)
+{
+    float c[9], n[9];
+    load9(elem(col, (I)((I)tri * 9)), c);
+    load9(elem(nrm, (I)((I)tri * 9)), n);
+    TriSetup s;
+    s.x0 = R.a.x; s.y0 = R.a.y; s.x1 = R.a.z; s.y1 = R.a.w;
+    s.x2 = R.b.x; s.y2 = R.b.y; s.z0 = R.b.z; s.z1 = R.b.w;
+    s.z2 = R.c.x;
+    s.l01 = R.d.x; s.l02 = R.d.y; s.l11 = R.d.z; s.l12 = R.d.w;
+    s.l21 = R.e.x; s.l22 = R.e.y; s.l03 = R.e.z; s.l13 = R.e.w;
+    s.l23 = R.f.x; s.r1 = R.f.y; s.r2 = R.f.z; s.r3 = R.f.w;
+    s.rej1 = s.rej2 = s.rej3 = 0.0f;
+    s.fast = (__float_as_uint(R.c.w) & kRecFast) != 0;
+    float n1, n2, n3, b1, b2, b3;
+    numerators(s, X, Y, n1, n2, n3);
+    quotients(s, n1, n2, n3, true, b1, b2, b3);
+    store_fragment(interp(s.z0, s.z1, s.z2, b1, b2, b3), c, n, b1, b2, b3, Lt, pix, zb, cb, nb);
+}
+
+// The record a 16-lane group is sweeping.  T = TriXYZ (small records: the edge constants are
+// hoisted by the compiler) or TriSetup (large records: with the two division shortcuts).
+template <typename T>
+struct Work {
+    T s;
+    uint32_t id;
+    int bx0, by0, bx1, by1;  // clipped pixel box [bx0, bx1) x [by0, by1)
+    int nbx, nblk;           // 4x4 blocks across, in total
+};
+
+CR_DEV int box_w(uint32_t wh) { return (int)(wh & 0xFFFF); }
+CR_DEV int box_h(uint32_t wh) { return (int)(wh >> 16); }
+// WorkQueue::box: tile-local packed box <-> (xy, wh) in frame coordinates (xy = x0 | y0 << 16, wh = w | h << 16)
+CR_DEV uint32_t pack_box(uint32_t xy, uint32_t wh, int X0, int Y0)
+{
+    if (wh == 0) return 0u;
+    return (uint32_t)((int)(xy & 0xFFFF) - X0) | ((uint32_t)((int)(xy >> 16) - Y0) << 6) | ((wh & 0x7Fu) << 12) |
+           ((wh >> 16) << 19);
+}
+CR_DEV uint32_t packed_wh(uint32_t b) { return ((b >> 12) & 0x7Fu) | ((b >> 19) << 16); }
+CR_DEV uint32_t packed_xy(uint32_t b, int X0, int Y0)
+{
+    return (uint32_t)(X0 + (int)(b & 0x3Fu)) | ((uint32_t)(Y0 + (int)((b >> 6) & 0x3Fu)) << 16);
+}
+
+CR_DEV int blocks_of(uint32_t box_wh)
+{
+    return ((box_w(box_wh) + 3) >> 2) * ((box_h(box_wh) + 3) >> 2);
+}
+
+template <typename T>
+CR_DEV Work<T> load_work(const WorkQueue &q, int r, int X0, int Y0)
+{
+    Work<T> w;
+    w.id = q.tri[r];
+    const uint32_t xy = packed_xy(q.box[r], X0, Y0), wh = packed_wh(q.box[r]);
+    w.bx0 = xy & 0xFFFF;
+    w.by0 = xy >> 16;
+    const int bw = box_w(wh), bh = box_h(wh);
+    w.bx1 = w.bx0 + bw;
+    w.by1 = w.by0 + bh;
+    w.nbx = (bw + 3) >> 2;
+    w.nblk = w.nbx * ((bh + 3) >> 2);
+    const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r], q.x2[r], q.y2[r], q.z2[r]};
+    if constexpr (sizeof(T) == sizeof(TriXYZ)) w.s = t;
+    else w.s = make_setup(t, w.nblk >= 16);
+    return w;
+}
+
+// Flattened block index -> (wavefront, slot): the record holding block p of the batch.
+// (`scan` = the queue's wave-local exclusive prefix of the counts in question, `wo` the
+// exclusive prefix of the wavefronts' totals)
+CR_DEV int find_record(const uint32_t *scan, const uint32_t *wo, int p, uint32_t &first_block)
+{
+    int w = 0;
+#pragma unroll
+    for (int v = 1; v < kThreads / 64; ++v)
+        if ((uint32_t)p >= wo[v]) w = v;
+    const uint32_t pl = (uint32_t)p - wo[w];
+    int lo = w * 64, n = 64;   // last slot in [lo, lo + 64) with scan <= pl
+    while (n > 1) {
+        const int half = n >> 1;
+        if (scan[lo + half] <= pl) lo += half;
+        n -= half;
+    }
+    first_block = pl - scan[lo];
+    return lo;
+}
+
+// True if no pixel of the rectangle [xa, xb] x [ya, yb] can hold a fragment of the triangle: one
+// edge is "surely outside" (raster_math.h (1)) at the corner where its numerator is largest — the
+// numerators are monotone in X and in Y (every rounding step is), so every pixel of the rectangle
+// then fails that edge.  A NaN fails the test (keeps the rectangle); exact, never a guess.
+CR_DEV bool rect_surely_missed(const TriSetup &s, int xa, int xb, int ya, int yb)
+{
+    const float fxa = (float)xa, fxb = (float)xb, fya = (float)ya, fyb = (float)yb;
+    auto worst = [&](float l1, float l2, float ya_, float xb_, float rej) {
+        const float fy = (l1 * rej >= 0.0f) ? fyb : fya;
+        const float fx = (l2 * rej >= 0.0f) ? fxa : fxb;
+        return (l1 * (fy - ya_) - l2 * (fx - xb_)) * rej;
+    };
+    return worst(s.l01, s.l02, s.y2, s.x2, s.rej1) < -kRejTiny ||
+           worst(s.l11, s.l12, s.y0, s.x0, s.rej2) < -kRejTiny ||
+           worst(s.l21, s.l22, s.y1, s.x1, s.rej3) < -kRejTiny;
+}
+
+// Coarse pass of a large-record batch: one lane per dense 4x4 block; surviving blocks are
+// recorded in q.big.mask.
+CR_DEV void coarse_cull(WorkQueue &q, const uint32_t *wo, int total, int tid, int X0, int Y0,
+                                                      bool keep_all)
+{
+    for (int p = tid; p < total; p += kThreads) {
+        uint32_t first;
+        const int r = find_record(q.big.blk_scan, wo, p, first);
+        const TriSetup s = make_setup(TriXYZ{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
+                                             q.x2[r], q.y2[r], q.z2[r]}, false);
+        const uint32_t xy = packed_xy(q.box[r], X0, Y0), wh = packed_wh(q.box[r]);
+        const int nbx = (int)((wh & 0xFFFF) + 3) >> 2;
+        const int b = (int)first;
+        const int by = (int)(((float)b + 0.5f) * (1.0f / (float)nbx)), bx = b - by * nbx;
+        const int xa = (int)(xy & 0xFFFF) + (bx << 2), ya = (int)(xy >> 16) + (by << 2);
+        // t_k = num_k * rej_k (>= -2^-60 unless surely outside) grows with Y when l_k1 * rej_k > 0
+        // and with X when l_k2 * rej_k < 0: evaluate each edge at the corner where it is largest
+        const float fxa = (float)xa, fxb = (float)(xa + 3), fya = (float)ya, fyb = (float)(ya + 3);
+        auto worst = [&](float l1, float l2, float ya_, float xb_, float rej) {
+            const float fy = (l1 * rej >= 0.0f) ? fyb : fya;
+            const float fx = (l2 * rej >= 0.0f) ? fxa : fxb;
+            return (l1 * (fy - ya_) - l2 * (fx - xb_)) * rej;
+        };
+        const bool o1 = worst(s.l01, s.l02, s.y2, s.x2, s.rej1) < -kRejTiny;
+        const bool o2 = worst(s.l11, s.l12, s.y0, s.x0, s.rej2) < -kRejTiny;
+        const bool o3 = worst(s.l21, s.l22, s.y1, s.x1, s.rej3) < -kRejTiny;
+        if (keep_all || !(o1 || o2 || o3)) atomicOr(&q.big.mask[r], 1ull << b);
+    }
+}
+
+#ifdef CRENDER_STAMPS
+// Diagnostic build only: per-workgroup phase timestamps (s_memrealtime, 100 MHz, one clock for
+// the whole device — s_memtime has a base per XCD / clock domain) written to a buffer of their
+// own that no kernel reads.  16 words per workgroup of the raster grid: t_start, t_ready, t_swept,
+// t_end, list length, t_loads, t_queue, XCC id, tile, quadrant + 1.
+__device__ unsigned long long *g_stamps = nullptr;
+#define CR_STAMP(slot)                                                             \
+    do {                                                                           \
+        if (g_stamps && threadIdx.x == 0) g_stamps[stamp_base + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define CR_STAMP(slot) do { } while (0)
+#endif
+
+// Background of a tile rectangle (fused clear): z = 1e6, colour = normal = 0, winner = -1.
+// Full-width rows of 16-byte aligned planes go out as float4 stores (a 16-pixel tile is 448 of
+// them, two per thread, against seven dword stores per pixel); anything else pixel by pixel.
+// Every address is a uniform base (the rectangle's first pixel) plus a 32-bit per-thread offset:
+// the empty tiles are three quarters of a 1024^2 frame's workgroups and their instruction count
+// is part of the launch's (64-bit per-thread address arithmetic tripled it).
+// The background goes out write-through (sc1): a plain store allocates its line in the XCD's L2 and
+// 28 MB of them per 1024^2 frame push the lists and records the covered tiles are about to read out
+// of it; write-through stores cost the same and leave the L2 alone (T-Rex 1024^2: one frame alone
+// 22.8 -> 21.7 us, a launch that only clears 6.8 -> 6.2 us per frame in flight).
+typedef float cr_v4f __attribute__((ext_vector_type(4)));
+CR_DEV void st4(float *p, const float4 &v)
+{
+    const cr_v4f x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+}
+template <int TS>
+CR_DEV void clear_rect(float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
+                       int32_t *__restrict__ win, int W, int X0, int Y0, int X1, int Y1, bool vec, int tid)
+{
+    const size_t p0 = (size_t)Y0 * W + X0;
+    float *z0 = zb + p0, *c0 = cb + p0 * 3, *n0 = nb + p0 * 3;
+    int32_t *w0 = win ? win + p0 : nullptr;
+    const uint32_t t = (uint32_t)tid, uW = (uint32_t)W;
+    // (the constants are made here, opaquely: hoisted to the top of the kernel they would hold
+    // registers across the whole sweep)
+    float z1 = 1e6f, o1 = 0.0f;
+    asm volatile("" : "+v"(z1), "+v"(o1));
+    const float4 zv = make_float4(z1, z1, z1, z1), ov = make_float4(o1, o1, o1, o1);
+    const int4 wv = make_int4(-1, -1, -1, -1);
+    if (vec && X1 - X0 == TS) {
+        constexpr uint32_t ZQ = TS / 4, CQ = 3 * TS / 4;          // float4 per row: z, colour / normal
+        const uint32_t rows = (uint32_t)(Y1 - Y0);
+        if (TS == 16 && rows == 16) {
+            // thread t: piece t (z plane for t < 64, else colour piece t - 64) and piece t + 256
+            // (normal piece t, t < 192)
+            const uint32_t r1 = t / CQ, off1 = r1 * uW * 3 + (t - r1 * CQ) * 4;
+            if (t < 64) {
+                const uint32_t off0 = (t >> 2) * uW + (t & 3) * 4;
+                st4(z0 + off0, zv);
+                if (w0) *reinterpret_cast<int4 *>(w0 + off0) = wv;
+            } else {
+                const uint32_t k = t - 64, r0 = k / CQ;
+                st4(c0 + r0 * uW * 3 + (k - r0 * CQ) * 4, ov);
+            }
+            if (t < 192) st4(n0 + off1, ov);
+            return;
+        }
+        for (uint32_t i = t; i < rows * ZQ; i += kThreads) {
+            const uint32_t r = i / ZQ, off = r * uW + (i - r * ZQ) * 4;
+            st4(z0 + off, zv);
+            if (w0) *reinterpret_cast<int4 *>(w0 + off) = wv;
+        }
+        for (uint32_t i = t; i < rows * CQ; i += kThreads) {
+            const uint32_t r = i / CQ, off = r * uW * 3 + (i - r * CQ) * 4;
+            st4(c0 + off, ov);
+            st4(n0 + off, ov);
+        }
+        return;
+    }
+    const uint32_t w = (uint32_t)(X1 - X0), n = w * (uint32_t)(Y1 - Y0);
+    for (uint32_t p = t; p < n; p += kThreads) {
+        const uint32_t dy = p / w, off = dy * uW + (p - dy * w);
+        z0[off] = z1;
+        c0[off * 3] = o1; c0[off * 3 + 1] = o1; c0[off * 3 + 2] = o1;
+        n0[off * 3] = o1; n0[off * 3 + 1] = o1; n0[off * 3 + 2] = o1;
+        if (w0) w0[off] = -1;
+    }
+}
+
+// Per-frame view of the plan's tile lists, of the heavy-tile hand-off and of the dispatch-order
+// hint (k_raster side).
+struct TileLists {
+    const uint32_t *offs;       // scan path: list offsets into `entries`; null = direct bins
+    const uint32_t *count;      // direct bins: list lengths of THIS frame (never written here)
+    uint32_t *count_next;       // the other parity's counters: zeroed here for the next frame
+    const uint32_t *entries;    // scan path: triangle indices
+    const float4 *bins;         // direct bins: [ntiles][capacity] entries (BinEntry, three pieces each)
+    uint32_t capacity;
+    uint32_t T;                 // triangle count: list entries >= T (stale workspace) are ignored
+    // The triangle arrays may be a PERMUTATION of the caller's (crender_plan_set_triangle_order:
+    // tile-coherent order, so that list entries and winners gather near-streams).  Depth keys and
+    // the winner plane speak the caller's indices: orig_of[position] for the key, pos_of[index]
+    // back to the arrays.  Both null: the arrays are in the caller's order.
+    const uint32_t *orig_of, *pos_of;
+    // heavy tiles (see register_heavy): null / 0 when the launch has no helper workgroups
+    uint32_t *heavy_flag, *heavy_slots, *heavy_ctr_next;
+    int nhelp;                  // 3 * hmax helper workgroups
+    // dispatch order (see build_order): null when the launch is not ordered
+    int addr32;                  // framebuffer and attribute byte offsets fit 32 bits (see elem())
+    const uint32_t *order, *hint, *hint_bad;
+    uint32_t *order_next, *hint_next, *hint_bad_next;
+    unsigned char *grouped_next;
+    int vec_clear;              // planes 16-byte aligned and W % 4 == 0
+    Light light;                // CRENDER_FUSED_GURO: illumination applied as pixels are stored
+};
+
+// One record of a tile's list: projected vertices, triangle index, pixel box.  false = a stale
+// index (beyond the frame's triangle count): no work.
+CR_DEV bool load_record(const TileLists &L, const float *__restrict__ proj, const Geom &G, uint32_t idx,
+                        uint32_t &id, TriXYZ &t, uint32_t &ebx, uint32_t &eby)
+{
+    if (L.offs) {
+        id = L.entries[idx];
+        if (id >= L.T) return false;
+        t = load_tri(proj + (size_t)id * 9);
+        int xl, xr, yt, yb;
+        pixel_box(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2, G.W, G.H, xl, xr, yt, yb);
+        ebx = (uint32_t)xl | ((uint32_t)xr << 16);
+        eby = (uint32_t)yt | ((uint32_t)yb << 16);
+        return true;
+    }
+    const float4 *e = L.bins + (size_t)idx * 3;          // (BinEntry: 32- and 64-pixel tiles)
+    const float4 e0 = e[0], e1 = e[1], e2 = e[2];
+    t = TriXYZ{e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x};
+    id = __float_as_uint(e2.y);
+    ebx = __float_as_uint(e2.z);
+    eby = __float_as_uint(e2.w);
+    return id < L.T;
+}
+
+// ---- dispatch order from the previous frame's coverage -------------------------------------
+// The dispatcher starts workgroups strictly in grid order and a workgroup slot is held until its
+// stores are acknowledged, so in raster order the covered tiles of T-Rex 1024^2 (the middle rows
+// of the frame) started 1-3 us into the launch, behind a full chip of background tiles whose
+// 28 MB of clears also doubled the latency of every load the covered tiles then issued
+// (in-kernel stamps, profiles/r02).  Consecutive frames cover almost the same tiles, so each
+// raster launch leaves an ORDER for the next launch on the same plan: the tiles it found covered
+// first (longest lists first), one workgroup each, then the empty tiles in groups of kGroup per
+// workgroup, which are cleared without a look at their lists.  The order is only a hint about speed — it is always a permutation of the tiles
+// and every workgroup reads the actual list length of each tile it is handed, rasterizing it
+// if it is not empty after all — so a stale order (another model, a first frame) costs time,
+// never pixels.  Built by the launch's first workgroup from this frame's counters, which no
+// workgroup writes; read by the next launch (ping-pong buffers).
+constexpr int kGroup = 8;      // empty 16-pixel tiles cleared per workgroup of the order's last section
+constexpr int group_tiles(int ts) { return ts >= 32 ? kGroup / 4 : kGroup; }   // (the same 56 KB of 32-pixel tiles)
+CR_DEV void build_order(const uint32_t *__restrict__ count, int ntx, int nty,
+                        uint32_t *__restrict__ order_next, unsigned char *__restrict__ grouped_next,
+                        uint32_t *__restrict__ hint_next, uint32_t *scr, int group)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = ntx * nty;
+    // Step 1: each tile's class into LDS, one byte per tile (coalesced loads of the counters, all
+    // in flight).  Then the stable partition over contiguous chunks of the class bytes.  The
+    // launch cannot end before this workgroup does: it has to stay a few microseconds (a version
+    // that also looked at every empty tile's eight neighbours, to give tiles next to the model a
+    // workgroup of their own, took as long as the whole launch).
+    // classes: 0 heavy, 1 medium, 2 light lists (a workgroup each); 4 empty (cleared in groups)
+    unsigned char *cls = reinterpret_cast<unsigned char *>(scr + 32);
+    (void)nty;
+    for (int i = tid; i < ntiles; i += kThreads) {
+        const uint32_t c = count[i];
+        cls[i] = (unsigned char)(c >= kHeavyAt ? 0 : c >= 8u ? 1 : c ? 2 : 4);
+    }
+    __syncthreads();
+    auto cls_of = [&](int i) { return (int)cls[i]; };
+    // contiguous chunk of tiles per thread: the partition is stable, so each class keeps raster
+    // order (tiles that are cleared together stay neighbours in memory: scattered, the clears of
+    // T-Rex 1024^2 alone took 14 us instead of 7)
+    const int chunk = (ntiles + kThreads - 1) / kThreads;
+    const int i0 = tid * chunk, i1 = i0 + chunk < ntiles ? i0 + chunk : ntiles;
+    uint32_t n[5] = {0, 0, 0, 0, 0};
+    for (int i = i0; i < i1; ++i) {
+        const int k = cls_of(i);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) n[c] += (k == c);
+    }
+    uint32_t incl[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        incl[c] = wave_incl_sum(n[c]);
+        if (lane == 63) scr[wave * 5 + c] = incl[c];
+    }
+    __syncthreads();
+    uint32_t off[5], tot[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) {
+            const uint32_t t = scr[w * 5 + c];
+            if (w < wave) before += t;
+            total += t;
+        }
+        tot[c] = total;
+        off[c] = before + incl[c] - n[c];
+    }
+    uint32_t basec = 0;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) { off[c] += basec; basec += tot[c]; }
+    for (int i = i0; i < i1; ++i) {
+        const int k = cls_of(i);
+        uint32_t pos = 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            if (k == c) pos = off[c]++;
+        order_next[pos] = (uint32_t)i;
+        grouped_next[i] = k == 4;
+    }
+    if (tid == 0) {
+        const uint32_t ncov = tot[0] + tot[1] + tot[2];
+        hint_next[1] = ncov + tot[3];                       // tiles with a workgroup of their own
+        hint_next[2] = (tot[4] + group - 1) / group;        // workgroups that clear `group` tiles each
+        hint_next[0] = ncov ? 1u : 0u;     // an empty frame says nothing about the next one
+    }
+}
+
+// ---- pixel-owner sweep (32-pixel tiles whose whole list is ONE batch of large records) -------------
+// bunny 4096^2 and T-Rex 8192^2 are a few thousand triangles of thousands of pixels each: a tile
+// holds a handful of records that each cover much of it.  The block sweep above computes every
+// covered pixel's barycentrics twice (once for the depth key in LDS, once more in the resolve) and
+// pays an LDS atomic per fragment.  Here the tile's 1024 pixels are OWNED: thread t holds four pixels
+// of row t >> 3 — x = (t & 7) + 8 j, so that pixel j of a wavefront's 64 lanes is the j-th 8 x 8 block
+// of its band of eight rows — with their running minimum key AND the winning fragment's
+// barycentrics in registers; the wavefront walks the records in a uniform loop, passing over
+// records whose triangle certainly misses its band (one word per record, worked out once by the
+// record's thread: the block cull's corner test, raster_math.h (1), on box ∩ band), and the
+// divisions of pixel j are skipped when none of the block's 64 pixels is a candidate — a triangle
+// that touches part of a band costs the blocks it touches (with a thread's pixels side by side,
+// every one of the four passes found SOME lane live: 466 k division passes per bunny frame
+// instead of 333 k; raster 149 -> 133 us).  The resolve only interpolates: no LDS atomics, no
+// second set of divisions.  Same device functions, same keys, same tie rule as the sweeps above:
+// the planes are bit-identical.
+constexpr uint32_t kOwnFast = 1u << 4;     // flags word of a record: bits 0..3 bands, 4 window, 5..10 signs
+template <bool CLEAR, typename I>
+CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const float *__restrict__ col, const float *__restrict__ nrm,
+                       const uint32_t *__restrict__ pos_of, const Light &Lt,
+                       float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
+                       int32_t *__restrict__ win, int W, int X0, int Y0, int X1, int Y1)
+{
+    const int tid = threadIdx.x;
+    // a thread's four pixels lie 8 apart: pixel j of the wavefront's lanes is the j-th 8x8 block of its band
+    constexpr int XS = 8;
+    const int Xs = X0 + (tid & 7), Y = Y0 + (tid >> 3);
+    const bool row_in = Y < Y1;
+    const I pix0 = (I)((I)Y * (I)W + (I)Xs);
+    unsigned long long best[4];
+    float w1[4], w2[4], w3[4];          // the winner's barycentrics
+    uint32_t slots = 0;                 // the winner's record slot, one byte per pixel
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        best[j] = make_key(zord(1e6f), KEY_LOW_PRIOR);
+        if (!CLEAR && row_in && Xs + XS * j < X1) best[j] = make_key(zord_prior(*elem(zb, (I)(pix0 + XS * j))), KEY_LOW_PRIOR);
+        w1[j] = w2[j] = w3[j] = 0.0f;
+    }
+    const uint32_t my_band = 1u << (tid >> 6);
+    for (int r = 0; r < nrec; ++r) {
+        const float4 p0 = *reinterpret_cast<const float4 *>(pre + 8 * r);
+        const uint32_t flags = __float_as_uint(p0.w);
+        // the triangle cannot touch this wavefront's rows (no work, box or triangle elsewhere): uniform
+        if (!(flags & my_band)) continue;
+        const uint32_t wh = packed_wh(q.box[r]);
+        const uint32_t xy = packed_xy(q.box[r], X0, Y0);
+        const int bx0 = (int)(xy & 0xFFFF), by0 = (int)(xy >> 16);
+        const int bx1 = bx0 + box_w(wh), by1 = by0 + box_h(wh);
+        TriSetup st;
+        {   // the record's setup: differences anew (one operation each), the rest as its thread left it
+            const float4 p1 = *reinterpret_cast<const float4 *>(pre + 8 * r + 4);
+            st.x0 = q.x0[r]; st.y0 = q.y0[r]; st.z0 = q.z0[r];
+            st.x1 = q.x1[r]; st.y1 = q.y1[r]; st.z1 = q.z1[r];
+            st.x2 = q.x2[r]; st.y2 = q.y2[r]; st.z2 = q.z2[r];
+            st.l01 = st.x1 - st.x2; st.l02 = st.y1 - st.y2;
+            st.l11 = st.x2 - st.x0; st.l12 = st.y2 - st.y0;
+            st.l21 = st.x0 - st.x1; st.l22 = st.y0 - st.y1;
+            st.l03 = p0.x; st.l13 = p0.y; st.l23 = p0.z; st.fast = (flags & kOwnFast) != 0;
+            st.r1 = p1.x; st.r2 = p1.y; st.r3 = p1.z;
+            auto sign_of = [](uint32_t two_bits) { return two_bits == 1u ? 1.0f : two_bits == 2u ? -1.0f : 0.0f; };
+            st.rej1 = sign_of((flags >> 5) & 3u); st.rej2 = sign_of((flags >> 7) & 3u); st.rej3 = sign_of((flags >> 9) & 3u);
+        }
+        const uint32_t low = 0xFFFFFFFEu - q.tri[r];
+        const bool rows_ok = Y >= by0 && Y < by1;
+        // numerators() with the row's share of each edge worked out once for the four x-neighbours
+        // (the same operations in the same order: mu.pyx:34 before the division)
+        const float fy = (float)Y;
+        const float ry1 = st.l01 * (fy - st.y2), ry2 = st.l11 * (fy - st.y0), ry3 = st.l21 * (fy - st.y1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (X0 + XS * j >= bx1 || X0 + XS * j + XS <= bx0) continue;     // the box misses block j (uniform)
+            const int x = Xs + XS * j;
+            const float fx = (float)x;
+            const float n1 = ry1 - st.l02 * (fx - st.x2), n2 = ry2 - st.l12 * (fx - st.x0), n3 = ry3 - st.l22 * (fx - st.x1);
+            const bool live = rows_ok && (unsigned)(x - bx0) < (unsigned)(bx1 - bx0) && !surely_outside(st, n1, n2, n3);
+            if (wave_any(live)) {                                 // wavefront-uniform
+                if (live) {
+                    float b1, b2, b3;
+                    quotients(st, n1, n2, n3, true, b1, b2, b3);
+                    if (!(b1 < 0.0f || b2 < 0.0f || b3 < 0.0f)) {          // .pyx:215-216 (NaN passes)
+                        const float z = interp(st.z0, st.z1, st.z2, b1, b2, b3);
+                        if (z == z) {                                      // .pyx:220
+                            const unsigned long long k = make_key(zord(z), low);
+                            if (k < best[j]) {
+                                best[j] = k;
+                                w1[j] = b1; w2[j] = b2; w3[j] = b3;
+                                slots = (slots & ~(0xFFu << (8 * j))) | ((uint32_t)r << (8 * j));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- resolve: interpolate the winners and store (.pyx:219, 226-242)
+    if (!row_in || Xs >= X1) return;
+    float zv[4], cv[12], nv[12];
+    int32_t iv[4];
+    bool have[4];
+    uint32_t prev = 0xFFFFFFFFu;
+    float c[9], n[9], z0 = 0.f, z1 = 0.f, z2 = 0.f;
+    uint32_t id = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        have[j] = (uint32_t)best[j] != KEY_LOW_PRIOR;
+        zv[j] = 1e6f; iv[j] = -1;
+        cv[3 * j] = cv[3 * j + 1] = cv[3 * j + 2] = 0.0f;
+        nv[3 * j] = nv[3 * j + 1] = nv[3 * j + 2] = 0.0f;
+        if (have[j]) {
+            const uint32_t sl = (slots >> (8 * j)) & 0xFFu;
+            if (sl != prev) {            // (a thread's four pixels mostly share their winner)
+                prev = sl;
+                id = q.tri[sl];
+                z0 = q.z0[sl]; z1 = q.z1[sl]; z2 = q.z2[sl];
+                const uint32_t at = pos_of ? pos_of[id] : id;
+                load9(elem(col, (I)((I)at * 9)), c);
+                load9(elem(nrm, (I)((I)at * 9)), n);
+            }
+            const float b1 = w1[j], b2 = w2[j], b3 = w3[j];
+            zv[j] = interp(z0, z1, z2, b1, b2, b3);
+            float c0 = interp(c[0], c[3], c[6], b1, b2, b3);
+            float c1 = interp(c[1], c[4], c[7], b1, b2, b3);
+            float c2 = interp(c[2], c[5], c[8], b1, b2, b3);
+            const float n0 = interp(n[0], n[3], n[6], b1, b2, b3);
+            const float n1 = interp(n[1], n[4], n[7], b1, b2, b3);
+            const float n2 = interp(n[2], n[5], n[8], b1, b2, b3);
+            if (Lt.on) {
+                const float f = guro_factor(Lt, n0, n1, n2);
+                c0 *= f; c1 *= f; c2 *= f;
+            }
+            cv[3 * j] = c0; cv[3 * j + 1] = c1; cv[3 * j + 2] = c2;
+            nv[3 * j] = n0; nv[3 * j + 1] = n1; nv[3 * j + 2] = n2;
+            iv[j] = (int32_t)id;
+        }
+    }
+    float *zp = elem(zb, pix0), *cp = elem(cb, (I)(pix0 * 3)), *np_ = elem(nb, (I)(pix0 * 3));
+    int32_t *wp = win ? reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix0)) : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (Xs + XS * j >= X1 || !(CLEAR || have[j])) continue;
+        const int o = XS * j;
+        zp[o] = zv[j];
+        cp[3 * o] = cv[3 * j]; cp[3 * o + 1] = cv[3 * j + 1]; cp[3 * o + 2] = cv[3 * j + 2];
+        np_[3 * o] = nv[3 * j]; np_[3 * o + 1] = nv[3 * j + 1]; np_[3 * o + 2] = nv[3 * j + 2];
+        if (wp) wp[o] = iv[j];
+    }
+}
+
+// the batch: records array-of-structures on 16-pixel tiles (Rec16), else the WorkQueue
+template <int TS>
+constexpr size_t raster_queue_bytes()
+{
+    return TS == 16 ? sizeof(Rec16) * kBatch16 + sizeof(uint32_t) * (kThreads + 8) : sizeof(WorkQueue);
+}
+
+// Workgroup `b` of a raster launch (the kernels below hand in their LDS: k_frame runs binning
+// wavefronts of another frame in the same launch).
+template <int TS, bool CLEAR>
+CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict__ col,
+                        const float *__restrict__ nrm, const TileLists &L,
+                        float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
+                        int32_t *__restrict__ win, const Geom &G, int dbg_arg, int b,
+                        unsigned long long *key, unsigned char *qraw)
+{
+#ifdef CRENDER_STAMPS
+    // frames of a swap chain stamp into a region of their slot (bits 24..26 of dbg_arg), 8192 workgroups each
+    const size_t stamp_base = ((size_t)((dbg_arg >> 24) & 7) * 8192 + blockIdx.x) * 16;
+#endif
+    WorkQueue &q = *reinterpret_cast<WorkQueue *>(qraw);                 // (TS != 16 only)
+    Rec16 *recs = reinterpret_cast<Rec16 *>(qraw);                       // (TS == 16 only)
+    uint32_t *scan16 = reinterpret_cast<uint32_t *>(qraw + sizeof(Rec16) * kBatch16);
+    uint32_t *wave16 = scan16 + kThreads;
+    constexpr int kBatch = TS == 16 ? kBatch16 : kThreads;
+#ifdef CRENDER_DEV_KNOBS
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    // ---- which tile, and which part of it --------------------------------------------------
+    // grid = [order builder, if ordered][3 * hmax helpers][ntiles main workgroups, one tile each]
+    if (L.order_next) {
+        if (b == 0) {
+            build_order(L.count, G.ntx, G.nty, L.order_next, L.grouped_next, L.hint_next, reinterpret_cast<uint32_t *>(qraw), group_tiles(TS));
+            return;
+        }
+        b -= 1;
+    }
+    const bool helper = b < L.nhelp;
+    int quad = -1;               // -1 = the whole tile, 0..3 = one part of a heavy tile (half or quadrant)
+    int tile;
+    if (helper) {
+        // part 1..3 of the heavy tile registered in this workgroup's slot, if any
+        const uint32_t v = L.heavy_slots[b];
+        if (v == 0) return;                        // (same word for every thread: uniform)
+        tile = (int)v - 1;
+        quad = 1 + b % 3;
+    } else {
+        const int m = b - L.nhelp;
+        if (m == 0 && tid == 0) {
+            if (L.heavy_ctr_next) *L.heavy_ctr_next = 0;
+            *L.hint_bad_next = 0;
+        }
+        if (L.order && L.hint[0] && !*L.hint_bad) {
+            const int ns = (int)L.hint[1], ng = (int)L.hint[2];
+            if (m < ns) {
+                tile = (int)L.order[m];
+            } else {
+                // the order's last section: up to kGroup empty tiles per workgroup, cleared with two
+                // float4 stores per thread and tile (no list to look at: the binning pass vouches
+                // for their emptiness, see first_entry_of)
+                if (m >= ns + ng) return;
+                constexpr int kG = group_tiles(TS);
+                const int first = ns + (m - ns) * kG;
+                const int ntl = G.ntiles - first < kG ? G.ntiles - first : kG;
+                uint32_t tl[kG];
+#pragma unroll
+                for (int j = 0; j < kG; ++j) tl[j] = j < ntl ? L.order[first + j] : 0u;
+#pragma unroll
+                for (int j = 0; j < kG; ++j) {
+                    if (j >= ntl) break;
+                    const uint32_t tu = tl[j];
+                    const int gy = G.ntx_magic ? (int)__umulhi(tu, G.ntx_magic) : (int)tu / G.ntx;
+                    const int gx = (int)tu - gy * G.ntx;
+                    const int x0 = gx * TS, y0 = G.y0 + gy * TS;
+                    if (tid == 0) L.count_next[tu] = 0;
+                    if (CLEAR)
+                        clear_rect<TS>(zb, cb, nb, win, G.W, x0, y0, (x0 + TS < G.W) ? x0 + TS : G.W,
+                                       (y0 + TS < G.y1) ? y0 + TS : G.y1, L.vec_clear != 0, tid);
+                }
+                return;
+            }
+        } else {
+            tile = (dbg & 8) ? xcd_band_tile(m, G.ntiles) : m;
+            // Large grids: scatter the dispatch order (block b -> tile b * stride mod ntiles) so
+            // that a band of covered tiles is spread over the whole launch instead of arriving
+            // together (T-Rex 8192^2: 0.446 -> 0.402 ms).  Small grids are faster in raster order
+            // (T-Rex 1024^2: 24.7 vs 29.1 us), so the scatter starts at 32768 tiles.
+            if ((G.ntiles >= 32768) != ((dbg & 256) != 0)) {
+                // (b * stride) mod ntiles, the product below 2^48: quotient from a double multiply
+                // (exact product, at most one off after rounding), remainder fixed up
+                const unsigned long long P = (unsigned long long)m * (unsigned)G.tile_stride;
+                const unsigned long long qd = (unsigned long long)((double)P * G.inv_ntiles);
+                long long r = (long long)(P - qd * (unsigned)G.ntiles);
+                if (r < 0) r += G.ntiles;
+                if (r >= G.ntiles) r -= G.ntiles;
+                tile = (int)r;
+            }
+            // Workgroup b runs on XCD b % 8 and, there, on shader engine (b / 8) % 4, and the
+            // dispatcher places workgroups strictly in order.  With a tile row that is a multiple
+            // of 32 tiles a tile COLUMN would always meet the same (XCD, engine) pair: the pairs
+            // that own the columns under the model fill up with long-lived workgroups and stall
+            // the whole dispatch while a third of the chip's workgroup slots stand free.  Rotating
+            // row ty by 9 * ty columns walks every pair through every column (T-Rex 1024^2 raster
+            // 24.0 -> 21.6 us; the larger frames gain 0-2 %).
+            if (!(dbg & 512)) {
+                const int ty = G.ntx_magic ? (int)__umulhi((uint32_t)tile, G.ntx_magic) : tile / G.ntx;
+                const int t = tile - ty * G.ntx + 9 * ty;
+                const int tx = G.ntx_magic ? t - (int)__umulhi((uint32_t)t, G.ntx_magic) * G.ntx : t % G.ntx;
+                tile = ty * G.ntx + tx;
+            }
+        }
+    }
+    const int ty = G.ntx_magic ? (int)__umulhi((uint32_t)tile, G.ntx_magic) : tile / G.ntx;
+    const int tx = tile - ty * G.ntx;
+    int X0 = tx * TS, Y0 = G.y0 + ty * TS;
+    int X1 = (X0 + TS < G.W) ? (X0 + TS) : G.W;
+    int Y1 = (Y0 + TS < G.y1) ? (Y0 + TS) : G.y1;
+
+    CR_STAMP(0);
+#ifdef CRENDER_STAMPS
+    if (g_stamps && threadIdx.x == 0) {
+        g_stamps[stamp_base + 7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID
+        g_stamps[stamp_base + 8] = (unsigned long long)tile;
+        g_stamps[stamp_base + 10] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+    // the tile's triangle list: a run of the scanned index array, or (direct bins, offs == null)
+    // a fixed-capacity slab of entries whose fill count k_setup_wave left in count[tile]
+    uint32_t beg, end;
+    if (L.offs) {
+        beg = L.offs[tile];
+        end = L.offs[tile + 1];
+        if (end > L.capacity) end = L.capacity;
+        if (beg > end) beg = end;
+    } else {
+        const uint32_t n = L.count[tile];
+        beg = (uint32_t)tile * L.capacity;
+        end = beg + (n < L.capacity ? n : L.capacity);
+    }
+    if (!helper) {
+        if (L.heavy_flag && L.heavy_flag[tile]) quad = 0;
+        // the other parity's counter of this tile: zero for the next frame
+        if (tid == 0) L.count_next[tile] = 0;
+    }
+    int rw = TS;                 // width of this workgroup's rectangle in the key plane's terms
+    if (quad >= 0) {
+        constexpr int HS = TS / 2;
+        if (end - beg >= quad_at(TS)) {         // four quadrants
+            X0 += (quad & 1) * HS; Y0 += (quad >> 1) * HS;
+            if (X1 > X0 + HS) X1 = X0 + HS;
+            rw = HS;
+        } else {                                // two halves; parts 2 and 3 have nothing to do
+            if (quad >= 2) {
+                if (tid == 0) L.heavy_slots[b] = 0;
+                return;
+            }
+            Y0 += quad * HS;
+        }
+        if (Y1 > Y0 + HS) Y1 = Y0 + HS;
+        if (X1 < X0) X1 = X0;
+        if (Y1 < Y0) Y1 = Y0;
+    }
+    if (dbg & 1) end = beg;   // ablation: no coverage work (development build)
+
+    const bool work = beg != end && X0 < X1 && Y0 < Y1;     // (uniform over the workgroup)
+    if (!work) {
+        // nothing to rasterize here: the rectangle keeps its content, or (fused clear) becomes
+        // background — no key plane, no barriers
+        if (CLEAR && X0 < X1 && Y0 < Y1) clear_rect<TS>(zb, cb, nb, win, G.W, X0, Y0, X1, Y1, L.vec_clear && quad < 0, tid);
+        CR_STAMP(3);
+    } else {
+    // 16-pixel tiles with direct bins (at most 65536 triangles): a depth key's low word carries
+    // the triangle index in its high half as usual and, in its low half, where the record sits
+    // in LDS — batch and slot — so that the resolve takes the winner's edge constants from there
+    const bool slotted = TS == 16 && !L.offs;
+    // first batch of the tile's list straight into registers
+    uint32_t cur_id = 0, cur_bx = 0, cur_by = 0;
+    TriXYZ cur_t{};
+    bool cur_ok = tid < kBatch && beg + tid < end;
+    if (cur_ok) cur_ok = load_record(L, proj, G, beg + tid, cur_id, cur_t, cur_bx, cur_by);
+    if (cur_ok && L.orig_of) cur_id = L.orig_of[cur_id];      // from here on: the caller's index
+
+    // depth keys of the tile: the prior buffer value (or the cleared value) per pixel
+    // (32-pixel tiles: once it is known that the tile is not the pixel owners', see below)
+    auto init_keys = [&]() {
+        const unsigned long long key_clear = make_key(zord(1e6f), KEY_LOW_PRIOR);
+        for (int p = tid; p < TS * TS; p += kThreads) {
+            unsigned long long k = key_clear;
+            if (!CLEAR) {
+                const int x = X0 + (p % TS), y = Y0 + (p / TS);
+                if (x < X1 && y < Y1) k = make_key(zord_prior(zb[(size_t)y * G.W + x]), KEY_LOW_PRIOR);
+            }
+            key[p] = k;
+        }
+    };
+    if constexpr (TS != 32) init_keys();
+    CR_STAMP(1);
+#ifdef CRENDER_STAMPS
+    if (g_stamps && tid == 0) {
+        g_stamps[stamp_base + 4] = end - beg;
+        g_stamps[stamp_base + 9] = (unsigned long long)(quad + 1);
+    }
+#endif
+
+    for (uint32_t base = beg; base < end; base += kBatch) {
+        // ---- queue this batch: one record per thread, slot = thread index --------------
+        uint32_t box_xy = 0, box_wh = 0;
+        if (cur_ok) {
+            int xl = (int)(cur_bx & 0xFFFF), xr = (int)(cur_bx >> 16);
+            int yt = (int)(cur_by & 0xFFFF), yb = (int)(cur_by >> 16);
+            if (xl < X0) xl = X0;
+            if (xr > X1) xr = X1;
+            if (yt < Y0) yt = Y0;
+            if (yb > Y1) yb = Y1;
+            if (xl < xr && yt < yb) {
+                box_xy = (uint32_t)xl | ((uint32_t)yt << 16);
+                box_wh = (uint32_t)(xr - xl) | ((uint32_t)(yb - yt) << 16);
+                // A large triangle's pixel box covers about twice its area: a good part of the
+                // entries of a frame of large triangles (bunny 4096^2: 8 per tile) name tiles the
+                // triangle never touches.  Exact test on (box ∩ tile); not worth its ~80
+                // instructions for a small box.
+                if (TS >= 32 && (xr - xl) * (yb - yt) >= 256 &&
+                    rect_surely_missed(make_setup(cur_t, false), xl, xr - 1, yt, yb - 1))
+                    box_wh = 0;
+            }
+        }
+        const uint32_t key_low = slotted ? ((0xFFFFu - (cur_id & 0xFFFFu)) << 16) | ((((base - beg) / kBatch) & 0xFFu) << 8) | (uint32_t)tid
+                                         : 0xFFFFFFFEu - cur_id;
+#ifdef CRENDER_STAMPS
+        if (base == beg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CR_STAMP(5); }
+#endif
+        if constexpr (TS == 16) {
+            // Short batch on a 16-pixel tile: one PIXEL per thread, every thread walks the
+            // records (LDS broadcast reads), the running minimum stays in a register — no
+            // block scan, no record search, no LDS atomics.  A wavefront (4 rows of the tile)
+            // skips a record whose box misses its rows.
+            const uint32_t left = end - base;
+            const uint32_t pix_max = (dbg >> 16) & 0xFF ? (uint32_t)((dbg >> 16) & 0xFF) - 1u : kPixelPathRecords;
+            if (left <= pix_max) {
+                if (base != beg) __syncthreads();
+                if (tid < (int)left) put_rec16(&recs[tid], cur_t, key_low, box_xy, box_wh);
+                __syncthreads();
+#ifdef CRENDER_STAMPS
+                if (base == beg) CR_STAMP(6);
+#endif
+                const int px = X0 + (tid & 15), py = Y0 + (tid >> 4);
+                unsigned long long best = key[tid];
+                for (uint32_t r = 0; r < left; ++r) {
+                    const uint32_t wh = recs[r].box_wh & ~kRecFast;
+                    if (wh == 0) continue;
+                    const uint32_t xy = recs[r].box_xy;
+                    const int bx0 = (int)(xy & 0xFFFF), by0 = (int)(xy >> 16);
+                    const bool in = px >= bx0 && px < bx0 + (int)(wh & 0xFFFF) &&
+                                    py >= by0 && py < by0 + (int)(wh >> 16);
+                    if (!wave_any(in)) continue;
+                    const Rec16Regs R = load_rec16(&recs[r]);
+                    unsigned long long k;
+                    if (in && fragment16(R, px, py, k) && k < best) best = k;
+                }
+                key[tid] = best;
+                cur_ok = false;
+                continue;   // (this was the list's last batch)
+            }
+        }
+        // 16-pixel tiles: the work is flattened per PIXEL of the clipped boxes, not per block
+        // (see the sweep below); elsewhere per 16-pixel block
+        constexpr bool per_pixel = TS == 16;   // always the per-pixel sweep
+        constexpr bool either = TS == 32;      // counted both ways, the batch picks its sweep
+        // wave-inclusive scan of the work counts
+        // (per-pixel work is counted in ITEMS of kItemPixels / kItemPixels32 x-neighbours of a box row)
+        const uint32_t my_px = (uint32_t)(((box_w(box_wh) + kItemPixels32 - 1) / kItemPixels32) * box_h(box_wh));
+        // (16-pixel tiles: an item is a PAIR of x-neighbours of a box row, see the sweep)
+        const uint32_t my_blocks = per_pixel ? (uint32_t)(((box_w(box_wh) + kItemPixels - 1) / kItemPixels) * box_h(box_wh))
+                                             : (uint32_t)blocks_of(box_wh);
+        const uint32_t incl = wave_incl_sum(my_blocks);
+        uint32_t incl_px = my_px;
+        if constexpr (either) incl_px = wave_incl_sum(my_px);
+        // previous batch's sweeps must be over before the queue is overwritten (the first batch has
+        // none before it: the barrier behind the queue orders the key initialisation too)
+        if (base != beg) __syncthreads();
+        if constexpr (TS == 16) {
+            if (tid < kBatch) put_rec16(&recs[tid], cur_t, key_low, box_xy, box_wh);
+            scan16[tid] = incl - my_blocks;
+            if (lane == 63) wave16[wave] = incl;
+        } else {
+            q.x0[tid] = cur_t.x0; q.y0[tid] = cur_t.y0; q.z0[tid] = cur_t.z0;
+            q.x1[tid] = cur_t.x1; q.y1[tid] = cur_t.y1; q.z1[tid] = cur_t.z1;
+            q.x2[tid] = cur_t.x2; q.y2[tid] = cur_t.y2; q.z2[tid] = cur_t.z2;
+            q.tri[tid] = cur_id;
+            q.box[tid] = pack_box(box_xy, box_wh, X0, Y0);
+            if constexpr (!either) q.big.blk_scan[tid] = incl - my_blocks;     // (32-pixel tiles: once the sweep is chosen)
+            if (lane == 63) q.wave_blocks[wave] = incl;
+            if constexpr (either) {
+                if (lane == 63) q.wave_px[wave] = incl_px;
+            }
+        }
+        __syncthreads();  // queue complete
+#ifdef CRENDER_STAMPS
+        if (base == beg) CR_STAMP(6);
+#endif
+
+        // ---- sweep: the batch's work items, flattened and split evenly -------------------------
+        {
+            const int l = tid & 15, lx = l & 3, ly = l >> 2;
+            uint32_t wo[kThreads / 64 + 1];
+            wo[0] = 0;
+#pragma unroll
+            for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + (TS == 16 ? wave16[w] : q.wave_blocks[w]);
+            const int total = (int)wo[kThreads / 64];
+            const int nrec = (int)((end - base) < (uint32_t)kBatch ? (end - base) : (uint32_t)kBatch);
+            const uint32_t blk_excl = incl - my_blocks;
+            bool small_by_pixel = false;    // 32-pixel tiles: small records go per pixel too
+            if constexpr (either) small_by_pixel = total < 16 * nrec && !(dbg & 8192);
+            if constexpr (either) {
+                if (small_by_pixel) {
+                    // every record's thread works out, ONCE, what an item of its record would otherwise
+                    // work out again (9 items of two pixels per record on the 10 M small triangles:
+                    // 40 of an item's 175 vector instructions)
+                    const TriSetup mine = make_setup(cur_t, true);
+                    q.pre.l03[tid] = mine.l03; q.pre.l13[tid] = mine.l13; q.pre.l23[tid] = mine.l23;
+                    q.pre.r1[tid] = mine.fast ? mine.r1 : 0.0f; q.pre.r2[tid] = mine.r2; q.pre.r3[tid] = mine.r3;
+                    q.pre.px_scan[tid] = incl_px - my_px;
+                    __syncthreads();
+                }
+            }
+            // next batch: issue its loads now, they complete under the sweeps
+            const uint32_t nxt = base + kBatch + tid;
+            cur_ok = tid < kBatch && nxt < end;
+            if (cur_ok) cur_ok = load_record(L, proj, G, nxt, cur_id, cur_t, cur_bx, cur_by);
+            if (cur_ok && L.orig_of) cur_id = L.orig_of[cur_id];
+            // Per-pixel sweep: every pixel of every clipped box is one work item; thread t takes
+            // items t, t + 256, ...  All lanes work on a sample that lies in its box (a 4x4 block
+            // of a small box is mostly empty: 71 % of T-Rex 1024^2's block lanes were inside their
+            // box, 40-50 % on its busiest tiles, 35 % for the 10 M small triangles), and there is
+            // no per-group record walk.  The item's record comes from a two-level search of the
+            // prefix sums (most batches fit the first wavefront's 64 slots: then no wavefront
+            // selection and only log2 of the record count steps).
+            auto sweep_pixels = [&](const uint32_t *scan, const uint32_t *wo_, int total_) {
+                const int first_n = nrec <= 1 ? 1 : (nrec > 64 ? 64 : 1 << (32 - __clz(nrec - 1)));
+                for (int e = tid; e < total_; e += kThreads) {
+                    uint32_t i;
+                    int r;
+                    if (nrec <= 64) {
+                        int lo = 0;
+                        for (int n = first_n; n > 1;) {     // last slot with scan <= e
+                            const int half = n >> 1;
+                            if (scan[lo + half] <= (uint32_t)e) lo += half;
+                            n -= half;
+                        }
+                        r = lo;
+                        i = (uint32_t)e - scan[lo];
+                    } else {
+                        r = find_record(scan, wo_, e, i);
+                    }
+                    if constexpr (TS == 16) {
+                        const Rec16Regs R = load_rec16(&recs[r]);
+                        const uint32_t xy = __float_as_uint(R.c.z);
+                        const int bw = box_w(__float_as_uint(R.c.w));
+                        // kItemPixels samples per item — x-neighbours of one box row — share the
+                        // item's record search, its six LDS reads and its decode (a third of a
+                        // sample's instructions and most of an iteration's dependent LDS round
+                        // trips); a box width that is no multiple wastes part of an item per row.
+                        const int bwn = (bw + kItemPixels - 1) / kItemPixels;
+                        const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
+                        const int px0 = ((int)i - dy * bwn) * kItemPixels;
+                        const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
+                        unsigned long long *kp = &key[(y - Y0) * TS + (x - X0)];
+#pragma unroll
+                        for (int j = 0; j < kItemPixels; ++j) {
+                            unsigned long long k;
+                            if (fragment16(R, x + j, y, k) && (j == 0 || px0 + j < bw)) lds_key_min(kp + j, k);
+                        }
+                    } else {
+                        const uint32_t xy = packed_xy(q.box[r], X0, Y0);
+                        const int bw = box_w(packed_wh(q.box[r]));
+                        const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
+                                       q.x2[r], q.y2[r], q.z2[r]};
+                        const uint32_t id = q.tri[r];
+                        // the item's samples share its record search, its twelve LDS reads, the nine
+                        // edge constants and the refined reciprocals (raster_math.h (2)): per sample
+                        // that was 150 vector instructions, a pair costs 175
+                        TriSetup st;
+                        {
+                            st.x0 = t.x0; st.y0 = t.y0; st.z0 = t.z0; st.x1 = t.x1; st.y1 = t.y1; st.z1 = t.z1;
+                            st.x2 = t.x2; st.y2 = t.y2; st.z2 = t.z2;
+                            st.l01 = t.x1 - t.x2; st.l02 = t.y1 - t.y2;
+                            st.l11 = t.x2 - t.x0; st.l12 = t.y2 - t.y0;
+                            st.l21 = t.x0 - t.x1; st.l22 = t.y0 - t.y1;
+                            st.l03 = q.pre.l03[r]; st.l13 = q.pre.l13[r]; st.l23 = q.pre.l23[r];
+                            st.r1 = q.pre.r1[r]; st.r2 = q.pre.r2[r]; st.r3 = q.pre.r3[r];
+                            st.fast = st.r1 != 0.0f;
+                            st.rej1 = st.rej2 = st.rej3 = 0.0f;
+                        }
+                        const int bwn = (bw + kItemPixels32 - 1) / kItemPixels32;
+                        // i / bwn for i < 1024, bwn <= 32: the approximate reciprocal is exact enough
+                        const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
+                        const int px0 = ((int)i - dy * bwn) * kItemPixels32;
+                        const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
+                        unsigned long long *kp = &key[(y - Y0) * TS + (x - X0)];
+#pragma unroll
+                        for (int j = 0; j < kItemPixels32; ++j) {
+                            float n1, n2, n3;
+                            numerators(st, x + j, y, n1, n2, n3);
+                            unsigned long long k;
+                            if (fragment_from(st, id, n1, n2, n3, true, k) && (j == 0 || px0 + j < bw)) lds_key_min(kp + j, k);
+                        }
+                    }
+                }
+            };
+            if constexpr (TS == 32) {
+                // the whole list is this one batch of large records: the pixels' owners take it from here
+                if (base == beg && end - beg <= (uint32_t)kBatch && !small_by_pixel && !(dbg & 32768)) {
+                    // what depends on the triangle alone — the three denominators of mu.pyx:11-21 and
+                    // their refined reciprocals (raster_math.h (2)) — once per record, by the record's
+                    // thread, into the (unused) key plane: eight words per record
+                    // — and which of the four wavefronts' bands of eight rows the triangle can touch at all
+                    // (the exact rectangle test on box ∩ band, once per record instead of once per
+                    // record and wavefront), with the signs of the denominators and the window flag
+                    // in one word: a wavefront passes over a record that is not its business with
+                    // one LDS read
+                    float *pre = reinterpret_cast<float *>(key);
+                    if (tid < nrec) {
+                        const TriSetup st = make_setup(TriXYZ{q.x0[tid], q.y0[tid], q.z0[tid], q.x1[tid], q.y1[tid], q.z1[tid],
+                                                               q.x2[tid], q.y2[tid], q.z2[tid]}, true);
+                        const uint32_t bwh = packed_wh(q.box[tid]), bxy = packed_xy(q.box[tid], X0, Y0);
+                        uint32_t flags = st.fast ? kOwnFast : 0u;
+                        flags |= (uint32_t)(st.rej1 > 0.0f ? 1 : st.rej1 < 0.0f ? 2 : 0) << 5;
+                        flags |= (uint32_t)(st.rej2 > 0.0f ? 1 : st.rej2 < 0.0f ? 2 : 0) << 7;
+                        flags |= (uint32_t)(st.rej3 > 0.0f ? 1 : st.rej3 < 0.0f ? 2 : 0) << 9;
+                        if (bwh != 0) {
+                            const int bx0 = (int)(bxy & 0xFFFF), by0 = (int)(bxy >> 16);
+                            const int bx1 = bx0 + box_w(bwh), by1 = by0 + box_h(bwh);
+#pragma unroll
+                            for (int band = 0; band < 4; ++band) {
+                                const int ya = Y0 + 8 * band, yb = (ya + 8 < Y1) ? ya + 8 : Y1;
+                                if (by1 > ya && by0 < yb &&
+                                    !rect_surely_missed(st, bx0, bx1 - 1, by0 > ya ? by0 : ya, (by1 < yb ? by1 : yb) - 1))
+                                    flags |= 1u << band;
+                            }
+                        }
+                        float4 *o = reinterpret_cast<float4 *>(pre + 8 * tid);
+                        o[0] = make_float4(st.l03, st.l13, st.l23, __uint_as_float(flags));
+                        o[1] = make_float4(st.r1, st.r2, st.r3, 0.0f);
+                    }
+                    __syncthreads();
+                    if (L.addr32)
+                        owner_tile<CLEAR, uint32_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, zb, cb, nb, win,
+                                                    G.W, X0, Y0, X1, Y1);
+                    else
+                        owner_tile<CLEAR, size_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, zb, cb, nb, win,
+                                                  G.W, X0, Y0, X1, Y1);
+                    CR_STAMP(3);
+                    return;
+                }
+                if (base == beg) {
+                    init_keys();
+                    __syncthreads();
+                }
+            }
+            if constexpr (per_pixel) {
+                sweep_pixels(scan16, wo, total);
+            } else if (small_by_pixel) {
+                uint32_t wop[kThreads / 64 + 1];
+                wop[0] = 0;
+#pragma unroll
+                for (int w = 0; w < kThreads / 64; ++w) wop[w + 1] = wop[w] + q.wave_px[w];
+                sweep_pixels(q.pre.px_scan, wop, (int)wop[kThreads / 64]);
+            } else if (TS == 64 && ((total < 16 * nrec && !(dbg & 8192)) || (dbg & 128))) {
+                // Small records: each of the 16 lane groups takes one contiguous run of blocks,
+                // so a record is set up by (almost) one group only; tight loop, plain division.
+                const int chunk = (total + 15) >> 4;
+                int p = (tid >> 4) * chunk;
+                const int pend = (p + chunk < total) ? (p + chunk) : total;
+                if (p < pend) {
+                    uint32_t first;
+                    int r = find_record(q.big.blk_scan, wo, p, first);
+                    Work<TriXYZ> wk = load_work<TriXYZ>(q, r, X0, Y0);
+                    int b = (int)first;
+                    int by = (int)(((float)b + 0.5f) * (1.0f / (float)wk.nbx)), bx = b - by * wk.nbx;
+                    for (;;) {
+                        const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
+                        unsigned long long k;
+                        if (x < wk.bx1 && y < wk.by1 && fragment(wk.s, wk.id, x, y, k))
+                            lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                        if (++p >= pend) break;
+                        if (++b < wk.nblk) {
+                            if (++bx == wk.nbx) { bx = 0; ++by; }
+                        } else {
+                            // p < pend guarantees a later record with blocks
+                            do { wk = load_work<TriXYZ>(q, ++r, X0, Y0); } while (wk.nblk == 0);
+                            b = bx = by = 0;
+                        }
+                    }
+                }
+            } else {
+                // Large records (>= 16 blocks on average).  A triangle fills at most half of its
+                // pixel box, so first a coarse pass (one LANE per 4x4 block) discards blocks that
+                // lie entirely outside one edge; the survivors are then swept (one 16-lane GROUP
+                // per block): each wavefront takes a contiguous quarter of them and its four
+                // groups consecutive survivors, so the four blocks a wavefront works on at a
+                // time are neighbours.  In the sweep, lanes whose sign test is certainly negative
+                // are dead before any division (skipped wave-wide when nobody is live,
+                // raster_math.h (1)); the divisions that remain use the hoisted reciprocal (2).
+                const bool allow_rej = !(dbg & 32), allow_fast = !(dbg & 64);
+                if constexpr (TS <= 32) {          // a record has at most 64 blocks: one mask word
+                    q.big.mask[tid] = 0;
+                    if constexpr (either) q.big.blk_scan[tid] = blk_excl;
+                    __syncthreads();
+                    // ---- coarse pass.  Exact: each numerator is monotone in X and in Y (every
+                    // rounding step is), so its extreme over the block sits on a corner; a block
+                    // goes only if all four corners are "surely outside" the SAME edge, which is
+                    // then true of every pixel in it (raster_math.h (1)).
+                    coarse_cull(q, wo, total, tid, X0, Y0, (dbg & 4096) != 0);
+                    __syncthreads();
+                    // survivors per record -> the same two-level prefix as the block counts
+                    const uint32_t mine = (uint32_t)__popcll(q.big.mask[tid]);
+                    const uint32_t inc = wave_incl_sum(mine);
+                    q.big.blk_scan[tid] = inc - mine;
+                    if (lane == 63) q.wave_blocks[wave] = inc;
+                    __syncthreads();
+#pragma unroll
+                    for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + q.wave_blocks[w];
+                    const int work = (int)wo[kThreads / 64];       // surviving blocks
+                    // the survivors are almost all partly or fully covered, so wave-wide
+                    // rejection would rarely fire: plain contiguous runs, one per lane group
+                    const int chunk = (work + 15) >> 4;
+                    int p = (tid >> 4) * chunk;
+                    const int pend = (p + chunk < work) ? (p + chunk) : work;
+                    if (p < pend) {
+                        uint32_t first;
+                        int r = find_record(q.big.blk_scan, wo, p, first);
+                        Work<TriSetup> wk = load_work<TriSetup>(q, r, X0, Y0);
+                        float inv_nbx = 1.0f / (float)wk.nbx;
+                        // the record's survivor mask with everything before the current block cleared
+                        unsigned long long m = q.big.mask[r];
+                        for (uint32_t i = 0; i < first; ++i) m &= m - 1;
+                        for (;;) {
+                            const int b = __ffsll((long long)m) - 1;
+                            const int by = (int)(((float)b + 0.5f) * inv_nbx), bx = b - by * wk.nbx;
+                            const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
+                            float n1, n2, n3;
+                            numerators(wk.s, x, y, n1, n2, n3);
+                            unsigned long long k;
+                            if (x < wk.bx1 && y < wk.by1 && fragment_from(wk.s, wk.id, n1, n2, n3, allow_fast, k))
+                                lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                            if (++p >= pend) break;   // (p < pend guarantees another survivor)
+                            m &= m - 1;
+                            if (m == 0) {
+                                do { m = q.big.mask[++r]; } while (m == 0);
+                                wk = load_work<TriSetup>(q, r, X0, Y0);
+                                inv_nbx = 1.0f / (float)wk.nbx;
+                            }
+                        }
+                    }
+                } else {
+                    // 64-pixel tiles (up to 256 blocks per record): no cull, dense walk
+                    const int wchunk = (total + kThreads / 64 - 1) / (kThreads / 64);
+                    int p = wave * wchunk + ((tid >> 4) & 3);
+                    const int pend = ((wave + 1) * wchunk < total) ? ((wave + 1) * wchunk) : total;
+                    if (p < pend) {
+                        uint32_t first;
+                        int r = find_record(q.big.blk_scan, wo, p, first);
+                        Work<TriSetup> wk = load_work<TriSetup>(q, r, X0, Y0);
+                        int b = (int)first;
+                        float inv_nbx = 1.0f / (float)wk.nbx;
+                        for (;;) {
+                            const int by = (int)(((float)b + 0.5f) * inv_nbx), bx = b - by * wk.nbx;
+                            const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
+                            float n1, n2, n3;
+                            numerators(wk.s, x, y, n1, n2, n3);
+                            const bool live = x < wk.bx1 && y < wk.by1 &&
+                                              !(allow_rej && surely_outside(wk.s, n1, n2, n3));
+                            if (wave_any(live)) {   // wavefront-uniform
+                                unsigned long long k;
+                                if (live && fragment_from(wk.s, wk.id, n1, n2, n3, allow_fast, k))
+                                    lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                            }
+                            p += 4;
+                            if (p >= pend) break;
+                            b += 4;
+                            if (b >= wk.nblk) {
+                                do {
+                                    b -= wk.nblk;
+                                    wk = load_work<TriSetup>(q, ++r, X0, Y0);
+                                } while (b >= wk.nblk);
+                                inv_nbx = 1.0f / (float)wk.nbx;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    CR_STAMP(2);
+    // resolve: every pixel of the rectangle is written at most once (exactly once if CLEAR).
+    // A part's pixels are taken by the first wavefronts in rows of its own width.
+    const int npx = quad >= 0 ? rw * (TS / 2) : TS * TS;
+    auto resolve = [&](auto index_tag) {
+    using I = decltype(index_tag);
+    for (int p0 = tid; p0 < npx; p0 += kThreads) {
+        const int dy = rw == TS ? p0 / TS : p0 / (TS / 2), dx = p0 - dy * rw;
+        const int x = X0 + dx, y = Y0 + dy;
+        if (x >= X1 || y >= Y1) continue;
+        const int p = dy * TS + dx;
+        const I pix = (I)((I)y * (I)G.W + (I)x);
+        const uint32_t low = (uint32_t)key[p];
+        if (low == KEY_LOW_PRIOR) {
+            if (CLEAR) {
+                *elem(zb, pix) = 1e6f;
+                float *cp = elem(cb, (I)(pix * 3)), *np_ = elem(nb, (I)(pix * 3));
+                cp[0] = 0.0f; cp[1] = 0.0f; cp[2] = 0.0f;
+                np_[0] = 0.0f; np_[1] = 0.0f; np_[2] = 0.0f;
+                if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = -1;
+            }
+            continue;
+        }
+        uint32_t id = 0xFFFFFFFEu - low;
+        if (slotted) {
+            id = 0xFFFFu - (low >> 16);
+            if (((low >> 8) & 0xFFu) == (((end - beg - 1) / kBatch) & 0xFFu) && !(dbg & 2)) {
+                // the winner's record is still in LDS (it came with the last batch)
+                shade16_store(load_rec16(&recs[low & 0xFFu]), col, nrm, L.pos_of ? L.pos_of[id] : id, x, y, pix,
+                              zb, cb, nb, L.light);
+                if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = (int32_t)id;
+                continue;
+            }
+        }
+        if (dbg & 2) {   // ablation: no shading (development build)
+            *elem(zb, pix) = (float)id;
+            float *cp = elem(cb, (I)(pix * 3)), *np_ = elem(nb, (I)(pix * 3));
+            cp[0] = 1.0f; cp[1] = 1.0f; cp[2] = 1.0f;
+            np_[0] = 1.0f; np_[1] = 1.0f; np_[2] = 1.0f;
+            continue;
+        }
+        shade_and_store(proj, col, nrm, L.pos_of ? L.pos_of[id] : id, x, y, pix, zb, cb, nb, L.light);
+        if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = (int32_t)id;
+    }
+    };
+    if (L.addr32) resolve(uint32_t{}); else resolve(size_t{});
+    CR_STAMP(3);
+#ifdef CRENDER_STAMPS
+    if (g_stamps && threadIdx.x == 0) g_stamps[stamp_base + 11] = __builtin_amdgcn_s_memtime();
+#endif
+    }   // work
+    // hand-off words of a heavy tile go back to zero once every wavefront has read them
+    if (quad >= 0) {
+        __syncthreads();
+        if (tid == 0) {
+            if (!helper) L.heavy_flag[tile] = 0;
+            else L.heavy_slots[b] = 0;
+        }
+    }
+}
+
+template <int TS, bool CLEAR>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? kWavesPerSimd16 : TS == 32 ? kWavesPerSimd32 : 1)))
+void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
+              const float *__restrict__ nrm, TileLists L,
+              float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
+              int32_t *__restrict__ win, Geom G, int dbg_arg)
+{
+    __shared__ __attribute__((aligned(16))) unsigned long long key[TS * TS];   // (the pixel owners read it as float4)
+    __shared__ __attribute__((aligned(16))) unsigned char qraw[raster_queue_bytes<TS>()];
+    raster_body<TS, CLEAR>(proj, col, nrm, L, zb, cb, nb, win, G, dbg_arg, (int)blockIdx.x, key, qraw);
+}
+
+// One launch per frame for a stream of frames (crender_pipeline_*, direct bins): the raster pass of
+// frame i and, in its first `nsetup` workgroups, the binning pass of the NEXT frame on the same
+// stream — k_setup_wave's wavefronts, one per workgroup (threads 64..255 leave at once), working
+// into another plan.  Nothing in the launch depends on anything else in it.  The binning pass is a
+// latency chain of 216 wavefronts (T-Rex) that a launch of its own stretches to 8.6 us; here it
+// costs neither a launch nor the GPU's time between two launches of a stream.
+struct RasterArgs {
+    const float *proj, *col, *nrm;
+    TileLists L;
+    float *zb, *cb, *nb;
+    int32_t *win;
+    Geom G;
+    int dbg;
+};
+static_assert(kSetupWaveLds <= raster_queue_bytes<16>() && kSetupWaveLds <= raster_queue_bytes<32>(),
+              "a binning wavefront works in the raster workgroup's batch queue");
+struct FrameArgs {
+    RasterArgs R;
+    SetupArgs S;
+    int nsetup;
+};
+template <int TS, bool CLEAR>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? kWavesPerSimd16 : TS == 32 ? kWavesPerSimd32 : 1)))
+void k_frame(FrameArgs A)
+{
+    __shared__ __attribute__((aligned(16))) unsigned long long key[TS * TS];   // (the pixel owners read it as float4)
+    __shared__ __attribute__((aligned(16))) unsigned char qraw[raster_queue_bytes<TS>()];
+    if ((int)blockIdx.x < A.nsetup) {
+        if (threadIdx.x < kWave)
+            setup_wave_body<TS, true>(A.S.tri_in, A.S.nrm, A.S.proj_out, A.S.count, A.S.bins, A.S.dcap, A.S.hdr,
+                                      A.S.hv, A.S.T, A.S.P, A.S.G, (int64_t)blockIdx.x, qraw);
+        return;
+    }
+    raster_body<TS, CLEAR>(A.R.proj, A.R.col, A.R.nrm, A.R.L, A.R.zb, A.R.cb, A.R.nb, A.R.win, A.R.G, A.R.dbg,
+                           (int)blockIdx.x - A.nsetup, key, qraw);
+}
+
+// ---- second implementation: global 64-bit atomics ---------------------------------
+__global__ __launch_bounds__(kThreads) void k_keys_init(unsigned long long *__restrict__ keys,
+                                                        const float *__restrict__ zb,
+                                                        size_t first_pix, size_t npix, int clear)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    const unsigned long long key_clear = make_key(zord(1e6f), KEY_LOW_PRIOR);
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < npix; i += stride)
+        keys[first_pix + i] = clear ? key_clear : make_key(zord_prior(zb[first_pix + i]), KEY_LOW_PRIOR);
+}
+
+// one wavefront per triangle, 8x8 pixel steps over the pixel box
+__global__ __launch_bounds__(kThreads) void k_cover_atomic(const float *__restrict__ proj,
+                                                           const float *__restrict__ nrm,
+                                                           unsigned long long *__restrict__ keys,
+                                                           int64_t T, int W, int H, int y0, int y1)
+{
+    const int l = threadIdx.x & 63, lx = l & 7, ly = l >> 3;
+    const int64_t wave = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kThreads) >> 6;
+    for (int64_t t = wave; t < T; t += nwaves) {
+        const float *nn = nrm + t * 9;
+        if (backface(nn[2], nn[5], nn[8])) continue;
+        const TriXYZ tr = load_tri(proj + t * 9);
+        int xl, xr, yt, yb;
+        pixel_box(tr.x0, tr.y0, tr.x1, tr.y1, tr.x2, tr.y2, W, H, xl, xr, yt, yb);
+        if (xl - xr == 0 || yt - yb == 0) continue;  // .pyx:209
+        if (yt < y0) yt = y0;
+        if (yb > y1) yb = y1;
+        for (int yy = yt + ly; yy < yb; yy += 8)
+            for (int xx = xl + lx; xx < xr; xx += 8) {
+                unsigned long long k;
+                if (fragment(tr, (uint32_t)t, xx, yy, k)) {
+                    unsigned long long *slot = &keys[(size_t)yy * W + xx];
+                    if (k < *slot) atomicMin(slot, k);
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_resolve_global(const float *__restrict__ proj,
+                                                             const float *__restrict__ col,
+                                                             const float *__restrict__ nrm,
+                                                             const unsigned long long *__restrict__ keys,
+                                                             float *__restrict__ zb, float *__restrict__ cb,
+                                                             float *__restrict__ nb, int32_t *__restrict__ win,
+                                                             int W, size_t first_pix, size_t npix, int clear)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < npix; i += stride) {
+        const size_t pix = first_pix + i;
+        const uint32_t low = (uint32_t)keys[pix];
+        if (low == KEY_LOW_PRIOR) {
+            if (clear) {
+                zb[pix] = 1e6f;
+                cb[pix * 3] = 0.0f; cb[pix * 3 + 1] = 0.0f; cb[pix * 3 + 2] = 0.0f;
+                nb[pix * 3] = 0.0f; nb[pix * 3 + 1] = 0.0f; nb[pix * 3 + 2] = 0.0f;
+                if (win) win[pix] = -1;
+            }
+            continue;
+        }
+        const uint32_t id = 0xFFFFFFFEu - low;
+        shade_and_store(proj, col, nrm, id, (int)(pix % W), (int)(pix / W), pix, zb, cb, nb);
+        if (win) win[pix] = (int32_t)id;
+    }
+}
+
+// ---- self-check hook: shortcut (2) of raster_math.h against the plain division ----------
+__global__ __launch_bounds__(kThreads) void k_divcheck(const float *__restrict__ num,
+                                                       const float *__restrict__ den,
+                                                       float *__restrict__ out_tail,
+                                                       float *__restrict__ out_div, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const float a = num[i], d = den[i];
+        const bool win = in_div_window(a) && in_div_window(d);
+        out_tail[i] = win ? div_tail(a, d, refined_rcp(d)) : a / d;
+        out_div[i] = a / d;
+    }
+}
+
+template <int TS>
+int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, const float *d_nrm,
+                    float *d_z, float *d_color, float *d_normal, int32_t *d_winner, unsigned flags,
+                    hipStream_t s, const SetupArgs *with_setup = nullptr)
+{
+    const Layout &L = plan->L;
+    const Geom G = L.g;
+#ifdef CRENDER_STAMPS
+    const int dbg = dev_knobs() | (plan->stamp_slot << 24);
+#else
+    const int dbg = dev_knobs();
+#endif
+    const bool direct = plan->last_frame_direct;
+    const int par = plan->parity;
+    TileLists tl;
+    tl.offs = direct ? nullptr : plan->offs();
+    tl.count = plan->count(par);
+    tl.count_next = plan->count(par ^ 1);
+    tl.entries = plan->entries();
+    tl.bins = plan->direct();
+    tl.capacity = direct ? (uint32_t)L.direct_cap : (uint32_t)L.capacity;
+    tl.T = (uint32_t)plan->last_T;
+    tl.orig_of = plan->orig_of;
+    tl.pos_of = plan->pos_of;
+    const bool split = direct && L.hmax > 0 && plan->frame_lone && !(dbg & 2048);
+    tl.heavy_flag = split ? plan->hflag() : nullptr;
+    tl.heavy_slots = split ? plan->hslots() : nullptr;
+    tl.heavy_ctr_next = plan->hdr() + 2 + (par ^ 1);
+    tl.nhelp = split ? 3 * L.hmax : 0;
+    // ordered launches: read the order the previous launch left, leave one for the next
+    const bool ordered = direct && L.ordered && plan->frame_lone && !(dbg & 1024);
+    const int hp = plan->hint_par;
+    tl.order = ordered ? plan->order(hp) : nullptr;
+    tl.hint = plan->hint(hp);
+    tl.order_next = ordered ? plan->order(hp ^ 1) : nullptr;
+    tl.hint_next = plan->hint(hp ^ 1);
+    tl.grouped_next = ordered ? plan->grouped(hp ^ 1) : nullptr;
+    tl.hint_bad = plan->hdr() + 5 + par;
+    tl.hint_bad_next = plan->hdr() + 5 + (par ^ 1);
+    tl.addr32 = (uint64_t)G.H * (uint64_t)G.W * 12ull < (1ull << 32) &&
+                (uint64_t)(plan->last_T > 0 ? plan->last_T : 1) * 36ull < (1ull << 32);
+    if (ordered) plan->hint_par = hp ^ 1;
+    const uintptr_t any = (uintptr_t)d_z | (uintptr_t)d_color | (uintptr_t)d_normal | (uintptr_t)d_winner;
+    tl.vec_clear = (any & 15u) == 0 && (G.W & 3) == 0;
+    tl.light = Light{plan->light[0], plan->light[1], plan->light[2], (flags & CRENDER_FUSED_GURO) ? 1 : 0};
+    const unsigned grid = (unsigned)(G.ntiles + tl.nhelp + (ordered ? 1 : 0));
+    if constexpr (TS <= 32) {
+        if (with_setup) {
+            // this frame's raster pass and another plan's binning pass in one launch (k_frame)
+            const int nsetup = (int)((with_setup->T + kWave - 1) / kWave);
+            const RasterArgs ra{proj, d_col, d_nrm, tl, d_z, d_color, d_normal, d_winner, G, dbg};
+            const FrameArgs fa{ra, *with_setup, nsetup};
+            if (flags & CRENDER_FUSED_CLEAR)
+                hipLaunchKernelGGL((k_frame<TS, true>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, fa);
+            else
+                hipLaunchKernelGGL((k_frame<TS, false>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, fa);
+            CR_LAUNCH_CHECK("k_frame");
+            plan->awaiting[par ^ 1] = false;
+            return CRENDER_OK;
+        }
+    }
+    if (flags & CRENDER_FUSED_CLEAR)
+        hipLaunchKernelGGL((k_raster<TS, true>), dim3(grid), dim3(kThreads), 0, s, proj, d_col, d_nrm, tl,
+                           d_z, d_color, d_normal, d_winner, G, dbg);
+    else
+        hipLaunchKernelGGL((k_raster<TS, false>), dim3(grid), dim3(kThreads), 0, s, proj, d_col, d_nrm, tl,
+                           d_z, d_color, d_normal, d_winner, G, dbg);
+    CR_LAUNCH_CHECK("k_raster");
+    plan->awaiting[par ^ 1] = false;     // zeroed by this launch
+    return CRENDER_OK;
+}
+
+}  // namespace
+
+namespace crender_detail {
+
+int raster_pass(crender_plan *plan, const float *proj, const float *d_col, const float *d_nrm, int64_t T,
+                float *d_z, float *d_color, float *d_normal, int32_t *d_winner, unsigned flags,
+                void *stream, const SetupArgs *with_setup)
+{
+    if (!plan) return fail(CRENDER_EINVAL, "null plan");
+    if (T != plan->last_T) return fail(CRENDER_EINVAL, "T differs from the prepared frame's");
+    if ((flags & CRENDER_FUSED_GURO) && !(flags & CRENDER_FUSED_CLEAR))
+        return fail(CRENDER_EINVAL, "CRENDER_FUSED_GURO needs CRENDER_FUSED_CLEAR (the reference shades the whole "
+                                    "buffer after every render: only a frame that starts from cleared buffers "
+                                    "can shade its own pixels instead)");
+    if (!d_z || !d_color || !d_normal) return fail(CRENDER_EINVAL, "null framebuffer pointer");
+    if (T > 0 && (!proj || !d_col || !d_nrm)) return fail(CRENDER_EINVAL, "null triangle array");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return CR_BY_TILE(run_raster_pass<16>(plan, proj, d_col, d_nrm, d_z, d_color, d_normal, d_winner, flags, s, with_setup),
+                      run_raster_pass<32>(plan, proj, d_col, d_nrm, d_z, d_color, d_normal, d_winner, flags, s, with_setup),
+                      run_raster_pass<64>(plan, proj, d_col, d_nrm, d_z, d_color, d_normal, d_winner, flags, s));
+}
+
+}  // namespace crender_detail
+
+extern "C" {
+
+int crender_selfcheck_division(const float *d_num, const float *d_den, float *d_out_tail,
+                               float *d_out_div, int64_t n, void *stream)
+{
+    if (!d_num || !d_den || !d_out_tail || !d_out_div || n < 0)
+        return fail(CRENDER_EINVAL, "crender_selfcheck_division: bad argument");
+    if (n == 0) return CRENDER_OK;
+    hipLaunchKernelGGL(k_divcheck, dim3(grid_for((size_t)n, 8192)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), d_num, d_den, d_out_tail, d_out_div, (size_t)n);
+    CR_LAUNCH_CHECK("k_divcheck");
+    return CRENDER_OK;
+}
+
+size_t crender_atomic_scratch_bytes(int H, int W)
+{
+    if (H <= 0 || W <= 0) return 0;
+    return sizeof(unsigned long long) * (size_t)H * (size_t)W;
+}
+
+int crender_raster_atomic(const float *d_tri_proj, const float *d_col, const float *d_nrm, int64_t T,
+                          float *d_z, float *d_color, float *d_normal, int32_t *d_winner, int H, int W,
+                          int y0, int y1, unsigned flags, void *d_keys, void *stream)
+{
+    if (!d_z || !d_color || !d_normal || !d_keys || H <= 0 || W <= 0 || y0 < 0 || y1 > H || y0 >= y1 ||
+        T < 0 || T > 0xFFFFFFF0ll)
+        return fail(CRENDER_EINVAL, "crender_raster_atomic: bad argument");
+    if (T > 0 && (!d_tri_proj || !d_col || !d_nrm))
+        return fail(CRENDER_EINVAL, "crender_raster_atomic: null triangle array");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t first = (size_t)y0 * W, npix = (size_t)(y1 - y0) * W;
+    const int clear = (flags & CRENDER_FUSED_CLEAR) ? 1 : 0;
+    unsigned long long *keys = static_cast<unsigned long long *>(d_keys);
+    hipLaunchKernelGGL(k_keys_init, dim3(grid_for(npix, 4096)), dim3(kThreads), 0, s, keys, d_z, first,
+                       npix, clear);
+    CR_LAUNCH_CHECK("k_keys_init");
+    if (T > 0) {
+        hipLaunchKernelGGL(k_cover_atomic, dim3(grid_for((size_t)T * 64, 8192)), dim3(kThreads), 0, s,
+                           d_tri_proj, d_nrm, keys, T, W, H, y0, y1);
+        CR_LAUNCH_CHECK("k_cover_atomic");
+    }
+    hipLaunchKernelGGL(k_resolve_global, dim3(grid_for(npix, 8192)), dim3(kThreads), 0, s, d_tri_proj,
+                       d_col, d_nrm, keys, d_z, d_color, d_normal, d_winner, W, first, npix, clear);
+    CR_LAUNCH_CHECK("k_resolve_global");
+    return CRENDER_OK;
+}
+
+#ifdef CRENDER_STAMPS
+CRENDER_API int crender_debug_set_stamps(void *d_buf);
+// diagnostic build: point the kernels at a stamp buffer (ntiles * 8 u64), or detach with null
+int crender_debug_set_stamps(void *d_buf)
+{
+    unsigned long long *p = static_cast<unsigned long long *>(d_buf);
+    CR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof p));
+    return CRENDER_OK;
+}
+#endif
+
+}  // extern "C"

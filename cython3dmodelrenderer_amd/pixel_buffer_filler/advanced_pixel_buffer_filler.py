@@ -87,7 +87,7 @@ _current_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream",
 _current_device = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)
 
 
-_DIRECT_MAX_TRIANGLES = 1 << 16      # kDirectMaxTriangles of crender_hip.hip: beyond, count / scan / fill
+_DIRECT_MAX_TRIANGLES = 1 << 16      # kDirectMaxTriangles of csrc/plan.h: beyond, count / scan / fill
 
 
 class _FramePipeline:

@@ -1,19 +1,16 @@
 #!/bin/bash
 # A/B of library builds x CRENDER_DEBUG values on the GPU box, one process per arm:
 #   VARIANTS="name[:extra hipcc defines]..." DBGS="0 1024" WORKLOADS="trex1024" scripts/ab_variants.sh
-# a name with a directory variants/<name>/csrc builds those sources (copies of earlier revisions:
-# base = round 1, r02a = the first round-2 evidence commit); any other name builds the
-# working tree with -DCRENDER_DEV_KNOBS plus the given defines.  Per arm: bench.py line (pipelined
+# every name builds the working tree with -DCRENDER_DEV_KNOBS plus the given defines.  Per arm: bench.py line (pipelined
 # frames/s, single-stream frame, event-timed passes), rocprofv3 kernel averages of a single-stream
 # run, and one PMC pass (instruction counts).
 cd ${GRAFT_REPO_ROOT:-.}
 REPO=$(pwd)
-FLAGS=$(python -c "from cython3dmodelrenderer_amd import _build; print(' '.join(_build.HIPCC_FLAGS))")
 mkdir -p /tmp/abv
 for v in ${VARIANTS:-cur}; do
   name=${v%%:*}; defs=""; [ "$v" != "$name" ] && defs=$(echo "${v#*:}" | tr ',' ' ')
-  if [ -d variants/$name/csrc ]; then src=variants/$name/csrc/crender_hip.hip; defs="-DCRENDER_DEV_KNOBS $defs"; else src=cython3dmodelrenderer_amd/csrc/crender_hip.hip; [ -z "${NODEV:-}" ] && defs="-DCRENDER_DEV_KNOBS $defs"; fi
-  /opt/rocm/bin/hipcc $FLAGS $defs -o /tmp/abv/$name.so $src 2>/dev/null || echo "BUILD FAILED $name"
+  nodev=""; [ -n "${NODEV:-}" ] && nodev=--no-dev-knobs
+  scripts/dev_build.sh $nodev $defs --out /tmp/abv/$name.so > /dev/null || echo "BUILD FAILED $name"
 done
 line() { python -c "
 import json,sys,os
@@ -24,7 +21,6 @@ for w in ${WORKLOADS:-trex1024}; do
   for v in ${VARIANTS:-cur}; do
     name=${v%%:*}; export ABNAME=$name CRENDER_LIB=/tmp/abv/$name.so
     for g in ${DBGS:-0}; do
-      [ -d variants/$name/csrc ] && [ $g != 0 ] && continue
       export CRENDER_DEBUG=$g
       for rep in 1 2; do python bench.py --no-cpu-baseline --no-api-calls --workload $w --steps $s --warmup 3 2>/dev/null | line; done
       if [ -n "${PROF:-}" ]; then

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Register / scratch / LDS figures of every kernel of the HIP library, from the code-object
-metadata hipcc emits for gfx950 (no GPU needed): compiles csrc/crender_hip.hip device-only to
-assembly with the product flags and prints one row per kernel.
+metadata hipcc emits for gfx950 (no GPU needed): compiles every translation unit of csrc/ device-only
+to assembly with the product flags and prints one row per kernel.
 
   python scripts/kernel_regs.py [-D...] [--filter k_frame] [--asm /tmp/crender.s]
 """
@@ -22,10 +22,12 @@ def main():
     ap.add_argument("--asm", default="/tmp/crender_device.s")
     args, extra = ap.parse_known_args()
     flags = [f for f in _build.HIPCC_FLAGS if f not in ("-shared", "-fPIC") and not f.startswith("-Wl,")]
-    cmd = [_build._hipcc()] + flags + extra + ["--offload-device-only", "-S", "-o", args.asm,
-                                               os.path.join(_build.SRC_DIR, "crender_hip.hip")]
-    subprocess.check_call(cmd)
-    text = open(args.asm).read()
+    text = ""
+    for src in _build.SOURCES:
+        asm = args.asm + "." + os.path.splitext(src)[0]
+        cmd = [_build._hipcc()] + flags + extra + ["--offload-device-only", "-S", "-o", asm, os.path.join(_build.SRC_DIR, src)]
+        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+        text += open(asm).read()
     # amdhsa.kernels metadata: one YAML map per kernel
     rows = []
     for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", text, re.S):

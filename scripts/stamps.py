@@ -7,8 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from cython3dmodelrenderer_amd import _build
 dbg_lib = "/tmp/libcrender_hip_stamps.so"
-subprocess.check_call([_build._hipcc()] + _build.HIPCC_FLAGS + ["-DCRENDER_STAMPS"] + os.environ.get("STAMPS_DEFS", "").split() + ["-o", dbg_lib,
-                       os.path.join(_build.SRC_DIR, "crender_hip.hip")], stderr=subprocess.DEVNULL)
+_build.compile_library(dbg_lib, ["-DCRENDER_STAMPS"] + os.environ.get("STAMPS_DEFS", "").split(), quiet=True)
 _build.LIB_PATH = dbg_lib
 import torch
 from cython3dmodelrenderer_amd import _capi, scenes
@@ -21,7 +20,7 @@ if os.environ.get("STAMPS_TRI"):       # keep a slice of the model: "first:count
 L = _capi.load()
 f = AdvancedPixelBufferFiller(H, W, fov=fov, tile=tile)
 f.render_arrays(tri, col, nrm, clear=True); f.synchronize()
-ts = tile or (16 if H * W <= 1024 * 1024 else 32)   # pick_tile() of crender_hip.hip
+ts = tile or (16 if H * W <= 1024 * 1024 else 32)   # pick_tile() of abi.hip
 nt = ((W + ts - 1) // ts) * ((H + ts - 1) // ts)
 nhelp = 3 * min(nt // 8, 128) if ts == 16 else 0      # make_layout(): helper workgroups lead the grid
 nwg = nt + nhelp

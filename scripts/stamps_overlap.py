@@ -10,8 +10,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from cython3dmodelrenderer_amd import _build
 lib = "/tmp/libcrender_hip_stamps.so"
-subprocess.check_call([_build._hipcc()] + _build.HIPCC_FLAGS + ["-DCRENDER_STAMPS"] + os.environ.get("STAMPS_DEFS", "").split()
-                      + ["-o", lib, os.path.join(_build.SRC_DIR, "crender_hip.hip")], stderr=subprocess.DEVNULL)
+_build.compile_library(lib, ["-DCRENDER_STAMPS"] + os.environ.get("STAMPS_DEFS", "").split(), quiet=True)
 _build.LIB_PATH = lib
 import torch
 from cython3dmodelrenderer_amd import _capi, scenes

@@ -5,8 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from cython3dmodelrenderer_amd import _build
 dbg_lib = "/tmp/libcrender_hip_stamps.so"
-subprocess.check_call([_build._hipcc()] + _build.HIPCC_FLAGS + ["-DCRENDER_STAMPS", "-o", dbg_lib,
-                       os.path.join(_build.SRC_DIR, "crender_hip.hip")], stderr=subprocess.DEVNULL)
+_build.compile_library(dbg_lib, ["-DCRENDER_STAMPS"], quiet=True)
 _build.LIB_PATH = dbg_lib
 import torch
 from cython3dmodelrenderer_amd import _capi, scenes
