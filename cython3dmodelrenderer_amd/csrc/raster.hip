@@ -1269,6 +1269,45 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     // resolve: every pixel of the rectangle is written at most once (exactly once if CLEAR).
     // A part's pixels are taken by the first wavefronts in rows of its own width.
     const int npx = quad >= 0 ? rw * (TS / 2) : TS * TS;
+    // Tile-coherent triangle order: a winner is known by the caller's index, its record sits at
+    // pos_of[index].  That look-up is a 4-byte needle out of a table of T words, one 128-byte L2
+    // request per distinct winner of a wavefront's pixels — on the 10 M-triangle frame a quarter of
+    // the 3.0 GB the launch fetches, and the launch is bound by exactly that traffic (5.4 TB/s of L2
+    // requests, profiles/r04/fetch_calibration.txt).  Every winner is a record of THIS tile's list,
+    // whose entries (positions, a contiguous run) and their original indices (orig_of, near-contiguous)
+    // the sweep has just read: they go into a hash table in the batch queue's LDS, free now, and the
+    // pixels look their winners up there.  Lists too long for the table keep the global look-up.
+    constexpr uint32_t kHashSlots = (raster_queue_bytes<TS>() / sizeof(uint2)) >= 2048 ? 2048u : 1024u;
+    static_assert(kHashSlots * sizeof(uint2) <= raster_queue_bytes<TS>(), "the table takes the batch queue's place");
+    uint2 *hash_tab = reinterpret_cast<uint2 *>(qraw);
+    const bool hashed = L.pos_of && L.offs && end - beg <= kHashSlots / 2 && !(dbg & (1 << 21));
+    auto hash_of = [](uint32_t orig) { return (orig * 2654435761u) >> (kHashSlots == 2048u ? 21 : 22); };
+    if (hashed) {
+        for (uint32_t i = (uint32_t)tid; i < kHashSlots; i += kThreads) hash_tab[i] = make_uint2(0u, 0u);
+        __syncthreads();
+        for (uint32_t idx = beg + (uint32_t)tid; idx < end; idx += kThreads) {
+            const uint32_t at = L.entries[idx];
+            if (at >= L.T) continue;
+            const uint32_t tag = L.orig_of[at] + 1u;                     // (0 = empty slot)
+            for (uint32_t h = hash_of(tag - 1u);; h = (h + 1u) & (kHashSlots - 1u)) {
+                const uint32_t was = atomicCAS(&hash_tab[h].x, 0u, tag);
+                if (was == 0u || was == tag) { hash_tab[h].y = at; break; }
+            }
+        }
+        __syncthreads();
+    }
+    auto position_of = [&](uint32_t id) -> uint32_t {
+        if (!L.pos_of) return id;
+        if (hashed) {
+            uint32_t h = hash_of(id);
+            for (uint32_t probes = 0; probes < kHashSlots; ++probes, h = (h + 1u) & (kHashSlots - 1u)) {
+                const uint2 e = hash_tab[h];
+                if (e.x == id + 1u) return e.y;
+                if (e.x == 0u) break;
+            }
+        }
+        return L.pos_of[id];
+    };
     auto resolve = [&](auto index_tag) {
     using I = decltype(index_tag);
     for (int p0 = tid; p0 < npx; p0 += kThreads) {
@@ -1306,7 +1345,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             np_[0] = 1.0f; np_[1] = 1.0f; np_[2] = 1.0f;
             continue;
         }
-        shade_and_store(proj, col, nrm, L.pos_of ? L.pos_of[id] : id, x, y, pix, zb, cb, nb, L.light);
+        shade_and_store(proj, col, nrm, position_of(id), x, y, pix, zb, cb, nb, L.light);
         if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = (int32_t)id;
     }
     };

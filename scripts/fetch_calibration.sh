@@ -34,3 +34,21 @@ for k, stride in enumerate((9, 12, 16, 32)):
     print(f"stride {rec:3d} B: FETCH_SIZE {kb:12.0f} per launch | expected HBM bytes: {(touched(128) + idx_out) / 1e6:7.1f} MB at 128-B lines, "
           f"{(touched(64) + idx_out) / 1e6:7.1f} MB at 64-B | counter x 1 KB = {kb * 1024 / 1e6:7.1f} MB -> factor vs 128-B lines {(touched(128) + idx_out) / (kb * 1024):.2f}, vs 64-B {(touched(64) + idx_out) / (kb * 1024):.2f}")
 PY
+# second part: how large are the L2's read requests to the fabric for this pattern?  (request counts by size;
+# bounded: these derived counters need several replays)
+rm -rf /tmp/fetchcal2
+(cd /tmp && TMPDIR=/tmp timeout -k 10 240 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d /tmp/fetchcal2 -- $REPO/scripts/ubench/gather_stride > /tmp/fetchcal2.log 2>&1; echo "rc=$?")
+python - <<'PY'
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for f in glob.glob("/tmp/fetchcal2/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_gather" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+for name, rows in sorted(acc.items()):
+    rows.sort()
+    for k, stride in enumerate((36, 48, 64, 128)):
+        v = [x for _, x in rows[k * 10:(k + 1) * 10]]
+        if v:
+            print(f"{name:28s} stride {stride:3d} B: {sum(v) / len(v):14.0f} per launch")
+PY
