@@ -42,6 +42,12 @@ import time
 # when it is loaded — torch brings a copy — so they are set before anything else is imported.
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
+# (the CPUs this process may use, taken NOW: once libgomp is loaded it pins the main thread to the first
+# core, and the mask read later would say "two CPUs")
+try:
+    _ALLOWED_CPUS = sorted(os.sched_getaffinity(0))
+except AttributeError:
+    _ALLOWED_CPUS = list(range(os.cpu_count() or 1))
 
 import numpy as np
 
@@ -90,10 +96,7 @@ def cpu_model():
 
 def host_topology():
     """CPUs this process may run on and the physical cores behind them (/proc/cpuinfo)."""
-    try:
-        allowed = sorted(os.sched_getaffinity(0))
-    except AttributeError:
-        allowed = list(range(os.cpu_count() or 1))
+    allowed = _ALLOWED_CPUS
     cores = set()
     try:
         cpu = phys = core = None

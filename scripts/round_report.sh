@@ -3,7 +3,8 @@
 # (copy what is to be judged into profiles/rNN/ afterwards: gpurun_out/ is scratch)
 #   PART=a  smoke, pytest -m gpu, the bench lines
 #   PART=b  rocprofv3: kernel trace + PMC passes, single-stream (k_raster) and pipelined (k_frame)
-#   PART=all (default) both
+#   PART=c  the bench lines alone
+#   PART=all (default) everything
 cd ${GRAFT_REPO_ROOT:-.}
 PART=${PART:-all}
 OUT=gpurun_out/report; mkdir -p $OUT
@@ -35,6 +36,8 @@ fi
 if [ $PART = a ] || [ $PART = all ]; then
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
 timeout -k 10 1100 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu.log
+fi
+if [ $PART = a ] || [ $PART = c ] || [ $PART = all ]; then      # (c: the bench lines alone)
 python bench.py > $OUT/bench_trex1024.json 2> $OUT/bench_trex1024.err; echo "bench rc=$?"
 python bench.py --steps 20 --warmup 5 > $OUT/bench_trex1024_k20.json 2>/dev/null       # the driver's command line
 python bench.py --workload bunny4096 --steps 50 --warmup 5 > $OUT/bench_bunny4096.json 2>/dev/null
