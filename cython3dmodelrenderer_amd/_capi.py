@@ -10,7 +10,7 @@ import os
 
 from . import _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK, EINVAL, EHIP, ENOMEM = 0, 1, 2, 3
 FUSED_CLEAR = 1
 NO_DIRECT_BINS = 2
@@ -36,6 +36,7 @@ SIGNATURES = {
     "crender_plan_last_frame_direct": (_i32, [_vp]),
     "crender_plan_set_light": (_i32, [_vp, _f32p]),
     "crender_plan_set_triangle_order": (_i32, [_vp, _vp, _vp]),
+    "crender_plan_set_normal_z": (_i32, [_vp, _vp]),
     "crender_tile_order_keys": (_i32, [_vp, _i64, _f32p, _i32, _i32, _vp, _vp]),
     "crender_plan_timing_begin": (_i32, [_vp, _i32]),
     "crender_plan_timing_end": (_i32, [_vp, _vp, C.POINTER(_i32), C.POINTER(C.c_double),

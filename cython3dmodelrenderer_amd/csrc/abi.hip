@@ -259,6 +259,13 @@ int crender_plan_set_triangle_order(crender_plan *plan, const uint32_t *d_orig_o
     return CRENDER_OK;
 }
 
+int crender_plan_set_normal_z(crender_plan *plan, const float *d_nz)
+{
+    if (!plan) return fail(CRENDER_EINVAL, "crender_plan_set_normal_z: null plan");
+    plan->normal_z = d_nz;
+    return CRENDER_OK;
+}
+
 int crender_plan_set_light(crender_plan *plan, const float *light3)
 {
     if (!plan || !light3) return fail(CRENDER_EINVAL, "crender_plan_set_light: bad argument");

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(kWave) void k_setup_wave(const float *__restrict__ 
 template <int TS, bool PROJECT>
 __global__ __launch_bounds__(kWave) void k_count_wave(const float *__restrict__ tri_in,
                                                       const float *__restrict__ nrm,
+                                                      const float *__restrict__ nz3,
                                                       float *__restrict__ proj_out,
                                                       uint2 *__restrict__ trange,
                                                       uint32_t *__restrict__ count, int64_t T,
@@ -164,8 +165,13 @@ __global__ __launch_bounds__(kWave) void k_count_wave(const float *__restrict__ 
     for (int i = 0; i < kWaveHistTiles / kWave; ++i) hist[i * kWave + lane] = 0;   // (while the inputs are on their way)
     float nz0 = 0.0f, nz1 = 0.0f, nz2 = 0.0f;      // .pyx:202 looks at the normals' z only
     if (lane < n) {
-        const float *nn = nrm + (b0 + lane) * 9;
-        nz0 = nn[2]; nz1 = nn[5]; nz2 = nn[8];
+        if (nz3) {          // the components apart (crender_plan_set_normal_z): 12 contiguous bytes per triangle
+            const float *nn = nz3 + (b0 + lane) * 3;
+            nz0 = nn[0]; nz1 = nn[1]; nz2 = nn[2];
+        } else {
+            const float *nn = nrm + (b0 + lane) * 9;
+            nz0 = nn[2]; nz1 = nn[5]; nz2 = nn[8];
+        }
     }
     __syncthreads();
     uint2 r = make_uint2(kNoTiles, 0);
@@ -486,10 +492,10 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
     } else if (T > 0 && wave_scan) {
         const unsigned nwg = (unsigned)((T + kWave - 1) / kWave);
         if (project)
-            hipLaunchKernelGGL((k_count_wave<TS, true>), dim3(nwg), dim3(kWave), 0, s, d_tri, d_nrm,
+            hipLaunchKernelGGL((k_count_wave<TS, true>), dim3(nwg), dim3(kWave), 0, s, d_tri, d_nrm, plan->normal_z,
                                plan->proj(), plan->trange(), count, T, P, G);
         else
-            hipLaunchKernelGGL((k_count_wave<TS, false>), dim3(nwg), dim3(kWave), 0, s, d_tri, d_nrm,
+            hipLaunchKernelGGL((k_count_wave<TS, false>), dim3(nwg), dim3(kWave), 0, s, d_tri, d_nrm, plan->normal_z,
                                plan->proj(), plan->trange(), count, T, P, G);
         CR_LAUNCH_CHECK("k_count_wave");
     } else if (T > 0) {

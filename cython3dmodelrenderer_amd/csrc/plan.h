@@ -61,6 +61,7 @@ struct crender_plan {
     int hint_par = 0;             // order / hint buffer the next raster launch reads (it writes the other)
     float light[3] = {0.f, 0.f, 0.f};   // crender_plan_set_light (CRENDER_FUSED_GURO)
     const uint32_t *orig_of = nullptr, *pos_of = nullptr;   // crender_plan_set_triangle_order
+    const float *normal_z = nullptr;                        // crender_plan_set_normal_z
     bool frame_lone = true;       // the last bin pass belonged to a frame rendered for latency (no
                                   // CRENDER_OVERLAPPED_FRAMES): ordered dispatch and split heavy tiles
     uint32_t *hint(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_hint) + 4 * k; }

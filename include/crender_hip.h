@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CRENDER_ABI_VERSION 3
+#define CRENDER_ABI_VERSION 4
 #define CRENDER_API __attribute__((visibility("default")))
 
 enum {
@@ -144,6 +144,17 @@ CRENDER_API int crender_tile_order_keys(const float *d_tri, int64_t T, const flo
                                         uint32_t *d_keys, void *stream);
 CRENDER_API int crender_plan_set_triangle_order(crender_plan *plan, const uint32_t *d_orig_of,
                                                 const uint32_t *d_pos_of);
+
+/* Normal z components apart (no reference counterpart: a data-layout choice like the triangle order).
+ * The back-face test of .pyx:202 reads the z component of a triangle's three vertex normals — 12 of
+ * the 36 bytes of its d_nrm record, at a stride that drags every line of the array through the
+ * binning pass (360 MB per frame of 10 M triangles, a third of that pass's traffic).  A caller that
+ * keeps a resident model may hand the plan those components as an array of their own:
+ * d_nz float32 [T][3] = d_nrm[:, :, 2], in the order of the triangle arrays the frames are given
+ * (device memory that outlives the plan's frames; NULL = read d_nrm).  The test itself — the float
+ * sum and its comparison — still runs every frame, on the same values: results are unchanged.
+ * Used by the scan path's binning pass (scenes beyond the direct bins). */
+CRENDER_API int crender_plan_set_normal_z(crender_plan *plan, const float *d_nz);
 
 /* Light direction (host pointer to 3 floats, copied) for frames rendered with CRENDER_FUSED_GURO:
  * GuroIllumination.__init__'s light_direction (guro_illumination.py:6-18). */

@@ -1789,3 +1789,32 @@ def test_bench_launch_contract_two_ranks_frames():
                      "--warmup", "2", "--no-api-calls"], 2)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["workload"] == "trex1024"
     assert d["value"] > 0 and "cpu_baseline" in d and "roofline" in d
+
+
+@pytest.mark.gpu
+def test_normal_z_array_feeds_the_back_face_test(oracle):
+    """crender_plan_set_normal_z: the scan path's binning pass takes the normals' z components from the
+    array of their own (the filler makes it with its tile-coherent copy).  Same frame as without it;
+    and the array is what is read: with every component +1 in it, everything is culled."""
+    import ctypes as C
+    import torch
+    from cython3dmodelrenderer_amd import _capi
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    rng = np.random.default_rng(8)
+    T = (1 << 18) + 77
+    tri, col, nrm = random_soup(rng, T, 1024, size_px=(1, 6), frac_backface=0.3)
+    ref = oracle.OracleFiller(1024, 1024, fov=45)
+    ref.render_arrays(tri, col, nrm)
+    filler = AdvancedPixelBufferFiller(1024, 1024, fov=45)
+    filler.render_arrays(tri, col, nrm, clear=True)
+    assert filler._order is not None and filler._order[2].shape == (T, 3)
+    assert_bit_equal(filler._order[2].cpu().numpy(), filler._inputs[2].cpu().numpy()[:, :, 2], "nz = nrm[:, :, 2]")
+    assert_bit_equal(filler.get_z_buffer(), ref.z_buffer, "z with the components apart")
+    assert_bit_equal(filler.get_normals_buffer(), ref.normals_buffer, "normal")
+    plain = AdvancedPixelBufferFiller(1024, 1024, fov=45, presort=False)      # caller's order, normals read in place
+    plain.render_arrays(tri, col, nrm, clear=True)
+    assert plain._order is None
+    assert_bit_equal(plain.get_z_buffer(), ref.z_buffer, "z without")
+    filler._order[2].fill_(1.0)                  # every triangle now "faces away"
+    filler.render_frame(pipelined=False)
+    assert float(filler.get_z_buffer().min()) == 1e6, "the back-face test read the array it was given"
