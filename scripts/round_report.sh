@@ -12,7 +12,7 @@ OUT=gpurun_out/report; mkdir -p $OUT
 if [ $PART = b ] || [ $PART = all ]; then
 for w in trex1024 bunny4096 trex8192 synth10m; do
   rm -rf gpurun_out/prof_$w
-  s=20; [ $w = trex1024 ] && s=100; [ $w = synth10m ] && s=5
+  s=20; [ $w = trex1024 ] && s=100; [ $w = synth10m ] && s=40     # (enough launches that the cold first frames do not set the average)
   scripts/profile_gpu.sh $w $s > $OUT/profile_$w.log 2>&1
   python scripts/summarize_prof.py gpurun_out/prof_$w | grep -v "at::native\|rocclr\|^void" > $OUT/rocprof_$w.txt
   cp gpurun_out/prof_$w/trace/*/*kernel_stats.csv $OUT/${w}_kernel_stats.csv 2>/dev/null
