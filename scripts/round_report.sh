@@ -42,7 +42,7 @@ python bench.py > $OUT/bench_trex1024.json 2> $OUT/bench_trex1024.err; echo "ben
 python bench.py --steps 20 --warmup 5 > $OUT/bench_trex1024_k20.json 2>/dev/null       # the driver's command line
 python bench.py --workload bunny4096 --steps 50 --warmup 5 > $OUT/bench_bunny4096.json 2>/dev/null
 python bench.py --workload trex8192 --steps 30 --warmup 3 > $OUT/bench_trex8192.json 2>/dev/null
-python bench.py --workload synth10m --steps 10 --warmup 2 > $OUT/bench_synth10m.json 2>/dev/null
+python bench.py --workload synth10m --steps 40 --warmup 10 > $OUT/bench_synth10m.json 2>/dev/null     # (the first ~20 frames after the 1.5 GB upload run up to 15 % slower: K = 10, W = 2 gave 1 062-1 104 frames/s)
 python bench.py --workload cube256 --steps 200 > $OUT/bench_cube256.json 2>/dev/null
 fi
 ls $OUT
