@@ -1271,9 +1271,8 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     const int npx = quad >= 0 ? rw * (TS / 2) : TS * TS;
     // Tile-coherent triangle order: a winner is known by the caller's index, its record sits at
     // pos_of[index].  That look-up is a 4-byte needle out of a table of T words, one 128-byte L2
-    // request per distinct winner of a wavefront's pixels — on the 10 M-triangle frame a quarter of
-    // the 3.0 GB the launch fetches, and the launch is bound by exactly that traffic (5.4 TB/s of L2
-    // requests, profiles/r04/fetch_calibration.txt).  Every winner is a record of THIS tile's list,
+    // request per distinct winner of a wavefront's pixels — on the 10 M-triangle frame 676 MB of the
+    // 3.06 GB the launch fetched (profiles/r04/fetch_breakdown_synth10m.txt).  Every winner is a record of THIS tile's list,
     // whose entries (positions, a contiguous run) and their original indices (orig_of, near-contiguous)
     // the sweep has just read: they go into a hash table in the batch queue's LDS, free now, and the
     // pixels look their winners up there.  Lists too long for the table keep the global look-up.
