@@ -1240,7 +1240,10 @@ def test_device_model_texture_colors_match_host_model():
         assert_bit_equal(dev._vertices_by_triangles.cpu().numpy(), host._vertices_by_triangles, "negative face indices")
 
 
-@pytest.mark.parametrize("T,res,tile", [(300_000, 1024, 0), (300_000, 2048, 0), (40_000, 512, 0)])
+# (the 512^2 cases: tile lists longer than the resolve's LDS hash table takes — 1 024 entries on 32-pixel
+# tiles, 512 on 16-pixel ones — so that some or all tiles fall back to the global pos_of look-up)
+@pytest.mark.parametrize("T,res,tile", [(300_000, 1024, 0), (300_000, 2048, 0), (40_000, 512, 0),
+                                        (300_000, 512, 32), (300_000, 512, 16)])
 def test_tile_coherent_order_changes_nothing(oracle, T, res, tile):
     """Large models are kept in HBM sorted by screen tile (crender_plan_set_triangle_order); depth
     ties and the winner plane still speak the caller's triangle indices.  Small random triangles
