@@ -10,8 +10,8 @@ import os
 
 from . import _build
 
-ABI_VERSION = 4
-OK, EINVAL, EHIP, ENOMEM = 0, 1, 2, 3
+ABI_VERSION = 5
+OK, EINVAL, EHIP, ENOMEM, EBUSY = 0, 1, 2, 3, 4
 FUSED_CLEAR = 1
 NO_DIRECT_BINS = 2
 OVERLAPPED_FRAMES = 4
@@ -34,6 +34,8 @@ SIGNATURES = {
     "crender_plan_destroy": (None, [_vp]),
     "crender_plan_last_bin_usage": (_i32, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "crender_plan_last_frame_direct": (_i32, [_vp]),
+    "crender_plan_frame_ticket": (C.c_uint64, [_vp]),
+    "crender_plan_poll_bin_usage": (_i32, [_vp, C.c_uint64, C.POINTER(_i64), C.POINTER(_i64)]),
     "crender_plan_set_light": (_i32, [_vp, _f32p]),
     "crender_plan_set_triangle_order": (_i32, [_vp, _vp, _vp]),
     "crender_plan_set_normal_z": (_i32, [_vp, _vp]),

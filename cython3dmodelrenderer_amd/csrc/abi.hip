@@ -118,6 +118,24 @@ int tile_frame(crender_plan *plan, bool project, const float *d_tri, const float
     return CRENDER_OK;
 }
 
+// What the header words of a frame mean (crender_plan_last_bin_usage, crender_plan_poll_bin_usage).
+void usage_figures(crender_plan *plan, bool direct, uint32_t h0, uint32_t h1, uint32_t h4, int64_t *needed,
+                   int64_t *capacity)
+{
+    if (direct) {
+        // direct bins: per-tile figures.  h1 is sticky: the longest list that did not fit
+        // (0xFFFFFFFF = a triangle spans too many tiles).  On overflow this plan switches to
+        // the count / scan / fill path for good; the caller renders the frame again.
+        const int64_t cap = plan->L.direct_cap;
+        if (h1 > (uint32_t)cap) plan->direct_ok = false;  // h1 stays set: the answer is repeatable
+        if (needed) *needed = h1 > (uint32_t)cap ? (int64_t)h1 : 0;
+        if (capacity) *capacity = cap;
+        return;
+    }
+    if (needed) *needed = (int64_t)(((unsigned long long)h4 << 32) | h0);
+    if (capacity) *capacity = plan->L.capacity;
+}
+
 }  // namespace
 
 // =========================== C ABI ================================================
@@ -175,10 +193,24 @@ int crender_plan_create(crender_plan **out, int H, int W, int y0, int y1, int64_
     p->ws = static_cast<unsigned char *>(d_workspace);
     // header + per-tile counters start at zero; the frame kernels keep them zero
     hipError_t e = hipMemsetAsync(p->ws, 0, L.off_offs, static_cast<hipStream_t>(stream));
+    // the per-frame usage records: pinned, coherent host memory the raster launches write into
+    void *host = nullptr;
+    if (e == hipSuccess)
+        e = hipHostMalloc(&host, sizeof(uint32_t) * 4 * (kUsageRing + 2), hipHostMallocMapped | hipHostMallocCoherent);
     if (e != hipSuccess) {
         delete p;
-        return fail_hip(e, "hipMemsetAsync(workspace)");
+        return fail_hip(e, "crender_plan_create (workspace memset / pinned usage records)");
     }
+    std::memset(host, 0, sizeof(uint32_t) * 4 * (kUsageRing + 2));
+    p->usage = static_cast<uint32_t *>(host);
+    void *dev = nullptr;
+    e = hipHostGetDevicePointer(&dev, host, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(host);
+        delete p;
+        return fail_hip(e, "hipHostGetDevicePointer(usage records)");
+    }
+    p->usage_dev = static_cast<uint32_t *>(dev);
     *out = p;
     return CRENDER_OK;
 }
@@ -187,6 +219,7 @@ void crender_plan_destroy(crender_plan *plan)
 {
     if (!plan) return;
     for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
+    if (plan->usage) (void)hipHostFree(plan->usage);
     delete plan;
 }
 
@@ -231,22 +264,29 @@ int crender_plan_timing_end(crender_plan *plan, void *stream, int *frames, doubl
 int crender_plan_last_bin_usage(crender_plan *plan, void *stream, int64_t *needed, int64_t *capacity)
 {
     if (!plan) return fail(CRENDER_EINVAL, "null plan");
-    uint32_t h[5] = {0, 0, 0, 0, 0};
+    // (into the plan's own pinned memory: a pageable destination makes the runtime stage the copy)
+    volatile uint32_t *h = plan->usage + 4 * kUsageRing;       // (the two records behind the ring)
     hipStream_t s = static_cast<hipStream_t>(stream);
-    CR_HIP(hipMemcpyAsync(h, plan->hdr(), sizeof h, hipMemcpyDeviceToHost, s));
+    CR_HIP(hipMemcpyAsync(const_cast<uint32_t *>(h), plan->hdr(), 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     CR_HIP(hipStreamSynchronize(s));
-    if (plan->last_frame_direct) {
-        // direct bins: per-tile figures.  h[1] is sticky: the longest list that did not fit
-        // (0xFFFFFFFF = a triangle spans too many tiles).  On overflow this plan switches to
-        // the count / scan / fill path for good; the caller renders the frame again.
-        const int64_t cap = plan->L.direct_cap;
-        if (h[1] > (uint32_t)cap) plan->direct_ok = false;  // h[1] stays set: the answer is repeatable
-        if (needed) *needed = h[1] > (uint32_t)cap ? (int64_t)h[1] : 0;
-        if (capacity) *capacity = cap;
-        return CRENDER_OK;
-    }
-    if (needed) *needed = (int64_t)(((unsigned long long)h[4] << 32) | h[0]);
-    if (capacity) *capacity = plan->L.capacity;
+    usage_figures(plan, plan->last_frame_direct, h[0], h[1], h[4], needed, capacity);
+    return CRENDER_OK;
+}
+
+uint64_t crender_plan_frame_ticket(crender_plan *plan) { return plan ? plan->ticket : 0; }
+
+int crender_plan_poll_bin_usage(crender_plan *plan, uint64_t ticket, int64_t *needed, int64_t *capacity)
+{
+    if (!plan) return fail(CRENDER_EINVAL, "null plan");
+    if (ticket == 0 || ticket > plan->ticket || plan->ticket - ticket >= (uint64_t)kUsageRing)
+        return fail(CRENDER_EINVAL, "crender_plan_poll_bin_usage: no such frame (not launched yet, or more than "
+                                    "8 frames ago: its record has been reused)");
+    const int slot = (int)(ticket % kUsageRing);
+    const uint32_t *rec = plan->usage + 4 * slot;
+    // the record is ONE aligned 16-byte store of the launch: whole, or not there yet
+    const uint32_t seq = __atomic_load_n(rec, __ATOMIC_ACQUIRE);
+    if (seq != (uint32_t)ticket) return CRENDER_EBUSY;       // (not an error: no text)
+    usage_figures(plan, plan->usage_direct[slot], rec[1], rec[2], rec[3], needed, capacity);
     return CRENDER_OK;
 }
 

@@ -55,8 +55,10 @@ std::array<float, 16> p16(const at::Tensor &P)
 
 void *current_stream(const at::Device &dev) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream(); }
 
-// replaces: render_model (.pyx:92-104) — crender_render_model on torch's current stream
-void render_model(int64_t plan, const at::Tensor &tri, const at::Tensor &col, const at::Tensor &nrm,
+// replaces: render_model (.pyx:92-104) — crender_render_model on torch's current stream.
+// Returns the frame's number on the plan (crender_plan_frame_ticket): what crender_plan_poll_bin_usage
+// is asked about later.
+int64_t render_model(int64_t plan, const at::Tensor &tri, const at::Tensor &col, const at::Tensor &nrm,
                   const at::Tensor &P, at::Tensor z, at::Tensor color, at::Tensor normal,
                   const c10::optional<at::Tensor> &winner, int64_t flags)
 {
@@ -75,6 +77,7 @@ void render_model(int64_t plan, const at::Tensor &tri, const at::Tensor &col, co
                                Pm.data(), plane_ptr(z, "z", dev), plane_ptr(color, "color", dev),
                                plane_ptr(normal, "normal", dev), win, (unsigned)flags, current_stream(dev)),
           "crender_render_model");
+    return (int64_t)crender_plan_frame_ticket(reinterpret_cast<crender_plan *>(plan));
 }
 
 // crender_pipeline_bind with tensors

@@ -22,6 +22,7 @@ struct Layout {
     size_t off_hdr, off_count, off_hflag, off_hslots, off_hint, off_order, off_grouped, off_offs,
            off_trange, off_proj, off_entries, off_direct, total;
 };
+constexpr int kUsageRing = 8;
 constexpr int kOrderMaxTiles = 8192;   // ordered dispatch: the builder keeps one byte per tile in the batch queue's LDS
 constexpr int kMaxHeavyHelped32 = 512;
 constexpr int kMaxHeavyHelped = 128;   // +384 workgroups per raster launch (9 % at 1024 x 1024)
@@ -64,6 +65,15 @@ struct crender_plan {
     const float *normal_z = nullptr;                        // crender_plan_set_normal_z
     bool frame_lone = true;       // the last bin pass belonged to a frame rendered for latency (no
                                   // CRENDER_OVERLAPPED_FRAMES): ordered dispatch and split heavy tiles
+    // Bin-list usage of every frame without a host round trip (crender_plan_poll_bin_usage): each
+    // raster launch copies the header words crender_plan_last_bin_usage reads into a record of its
+    // own in PINNED host memory the plan owns — one 16-byte store by one thread of the launch,
+    // {frame number, hdr[0], hdr[1], hdr[4]} — so that the host learns of an overflow by reading its
+    // own memory: no copy command, no event, no synchronisation.  Ring of kUsageRing frames.
+    uint32_t *usage = nullptr;            // [kUsageRing + 2][4] (the last two: staging of the blocking query)
+    uint32_t *usage_dev = nullptr;        // the same memory as the device addresses it
+    uint64_t ticket = 0;                  // raster launches so far: the last frame's number
+    bool usage_direct[kUsageRing] = {};   // the frame of each record went through the direct bins
     uint32_t *hint(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_hint) + 4 * k; }
     uint32_t *order(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_order) + (size_t)k * L.g.ntiles; }
     unsigned char *grouped(int k) const { return ws + L.off_grouped + (size_t)k * L.g.ntiles; }

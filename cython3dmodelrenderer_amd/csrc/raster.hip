@@ -404,6 +404,12 @@ struct TileLists {
     unsigned char *grouped_next;
     int vec_clear;              // planes 16-byte aligned and W % 4 == 0
     Light light;                // CRENDER_FUSED_GURO: illumination applied as pixels are stored
+    // this frame's bin-usage record in the plan's pinned host memory (crender_plan_poll_bin_usage):
+    // {frame number, hdr[0], hdr[1], hdr[4]}, one 16-byte store by the launch's LAST main workgroup
+    // (in raster order a corner tile, in an ordered launch a group of empty tiles: nobody's critical path)
+    const uint32_t *hdr;
+    uint32_t *usage;
+    uint32_t usage_seq;
 };
 
 // One record of a tile's list: projected vertices, triangle index, pixel box.  false = a stale
@@ -721,6 +727,10 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
         if (m == 0 && tid == 0) {
             if (L.heavy_ctr_next) *L.heavy_ctr_next = 0;
             *L.hint_bad_next = 0;
+        }
+        if (m == G.ntiles - 1 && tid == 0) {
+            // (the binning pass that wrote these words ran in an earlier launch of the stream)
+            *reinterpret_cast<uint4 *>(L.usage) = make_uint4(L.usage_seq, L.hdr[0], L.hdr[1], L.hdr[4]);
         }
         if (L.order && L.hint[0] && !*L.hint_bad) {
             const int ns = (int)L.hint[1], ng = (int)L.hint[2];
@@ -1540,6 +1550,13 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     const uintptr_t any = (uintptr_t)d_z | (uintptr_t)d_color | (uintptr_t)d_normal | (uintptr_t)d_winner;
     tl.vec_clear = (any & 15u) == 0 && (G.W & 3) == 0;
     tl.light = Light{plan->light[0], plan->light[1], plan->light[2], (flags & CRENDER_FUSED_GURO) ? 1 : 0};
+    // this launch's usage record (crender_plan_poll_bin_usage)
+    plan->ticket++;
+    const int uslot = (int)(plan->ticket % kUsageRing);
+    plan->usage_direct[uslot] = direct;
+    tl.hdr = plan->hdr();
+    tl.usage = plan->usage_dev + 4 * uslot;
+    tl.usage_seq = (uint32_t)plan->ticket;
     const unsigned grid = (unsigned)(G.ntiles + tl.nhelp + (ordered ? 1 : 0));
     if constexpr (TS <= 32) {
         if (with_setup) {

@@ -90,6 +90,39 @@ _current_device = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device
 _DIRECT_MAX_TRIANGLES = 1 << 16      # kDirectMaxTriangles of csrc/plan.h: beyond, count / scan / fill
 
 
+class _Stage:
+    """One staging slot of numpy inputs: pinned host [3, T, 3, 3] -> device [3, T, 3, 3], ONE copy.
+    A slot made for `cap` triangles serves any T <= cap (the arrays are the first 27 T floats of it)."""
+    __slots__ = ("cap", "T", "_pin", "_dev", "pin", "host", "dev", "done", "busy")
+
+    def __init__(self, cap, device):
+        self.cap = max(int(cap), 1)
+        with torch.cuda.device(device):
+            self._pin = torch.empty(27 * self.cap, dtype=torch.float32, pin_memory=True)
+            self._dev = torch.empty(27 * self.cap, dtype=torch.float32, device=device)
+            self.done = torch.cuda.Event()       # the last copy out of the pinned side has been read
+        self.busy = False
+        self.T = -1
+
+    def shape(self, T):
+        if T != self.T:
+            self.T = T
+            self.pin = self._pin[:27 * T].view(3, T, 3, 3)
+            self.dev = self._dev[:27 * T].view(3, T, 3, 3)
+            self.host = self.pin.numpy()
+        return self
+
+
+class _Frame:
+    """A launched frame whose bin lists have not been verified: its number on the plan, and what a
+    redo needs — the flags and the inputs it was rendered from, kept alive."""
+    __slots__ = ("ticket", "flags", "inputs", "order", "private", "light", "stage")
+
+    def __init__(self, ticket, flags, inputs, order, private, light, stage):
+        self.ticket, self.flags, self.inputs, self.order = ticket, flags, inputs, order
+        self.private, self.light, self.stage = private, light, stage
+
+
 class _FramePipeline:
     """Swap chain for ``render_frame`` (``crender_pipeline_*``): frame i renders on the library's
     stream i % depth with plan i % depth into framebuffer set i % depth, so up to `depth` frames
@@ -269,10 +302,10 @@ class AdvancedPixelBufferFiller:
         self._host_pin = {}            # name -> pinned host tensor behind the mirror
         self._host_fresh = False       # mirrors equal the device buffers
         self._host_exposed = False     # a mirror was handed out and may have been edited
-        self._stage = None             # (pinned [3, T, 3, 3], device [3, T, 3, 3]): numpy inputs' way up
-        self._stage_done = None        # event: the staging buffer's last copy has left the host
+        self._stages = []              # numpy inputs' way up: up to two _Stage (pinned + device [3, T, 3, 3])
+        self._inputs_stage = None      # the staging slot the resident inputs live in, if any
         self._sort_cache = None        # (key of caller-owned tensors, sorted inputs, order)
-        self._unverified = False       # a frame was launched whose bin lists have not been checked
+        self._pending = []             # frames launched whose bin lists have not been verified, oldest first
         self._redone = False
         # Tile-coherent copy of large models (crender_plan_set_triangle_order): None = from 2^18
         # triangles on, True / False = always / never.  Made once per upload; results do not change.
@@ -324,7 +357,7 @@ class AdvancedPixelBufferFiller:
         if self._plan and T <= self._plan_max_T and capacity <= self._plan_capacity:
             return
         if self._plan:
-            if self._unverified and not self._checking:
+            if self._pending and not self._checking:
                 self._check_bins()         # (may replace the plan itself: start over)
                 return self._ensure_plan(T, capacity)
             torch.cuda.current_stream(self.device).synchronize()
@@ -382,17 +415,30 @@ class AdvancedPixelBufferFiller:
     def _win_ptr(self):
         return self.winner_buffer.data_ptr() if self.winner_buffer is not None else None
 
-    def _launch(self, flags, inputs=None, private=False, generation=None):
+    def _launch(self, flags, inputs=None, private=False, generation=None, stage=None):
         self._join_pipe()
-        if self._unverified and not self._checking and not (flags & _capi.FUSED_CLEAR):
-            # This frame composites on top of the previous one.  If that one overflowed its bin
-            # lists it has to be redone NOW, from its own inputs: afterwards the buffers would
-            # hold this frame too, and replaying the earlier model on top of a later one is not
-            # the reference's result (the later call must win equal depths).
-            self._check_bins()
         if inputs is not None:
             self._inputs, self._order = self._tile_coherent(inputs, bool(private), generation)
             self._inputs_private = bool(private) or self._order is not None
+            # (a tile-coherent copy is a tensor of its own: the staging slot is free again)
+            self._inputs_stage = stage if self._order is None else None
+        if not self._checking:
+            if flags & _capi.FUSED_CLEAR:
+                # whatever an earlier frame dropped is overwritten by this one
+                self._pending.clear()
+            elif self._pending:
+                # This frame composites on top of the pending ones.  One of those that overflowed its
+                # bin lists has to be redone from ITS OWN inputs, in its place in the sequence (a later
+                # call must win equal depths): looked at now, without waiting, if its record has landed;
+                # otherwise the check is put off — the pending frames keep their inputs alive, and
+                # _settle replays the whole sequence in order if it finds an overflow later.  Inputs
+                # somebody else may rewrite (the caller's device tensors) cannot be kept: wait for them.
+                self._settle(block=not all(f.private for f in self._pending) or len(self._pending) >= 6)
+        self._submit(flags)
+
+    def _submit(self, flags):
+        """Launch one frame of the resident inputs on the single-stream plan; the frame joins the
+        pending list with its number on the plan (crender_plan_frame_ticket)."""
         tri, col, nrm = self._inputs
         T = tri.shape[0]
         self._ensure_plan(T)
@@ -404,6 +450,7 @@ class AdvancedPixelBufferFiller:
             _capi.check(self._lib.crender_plan_set_normal_z(self._plan, None if o is None else o[2].data_ptr()),
                         "crender_plan_set_normal_z")
             self._plan_order = (self._plan.value, id(o))
+        flags &= ~_capi.FUSED_GURO
         if (flags & _capi.FUSED_CLEAR) and self._fused_light is not None:
             if self._plan_light != (self._plan.value, self._fused_light):
                 _capi.check(self._lib.crender_plan_set_light(self._plan, (C.c_float * 3)(*self._fused_light)),
@@ -411,12 +458,13 @@ class AdvancedPixelBufferFiller:
                 self._plan_light = (self._plan.value, self._fused_light)
             flags |= _capi.FUSED_GURO
         # (the extension unwraps the tensors, takes torch's current stream of their device and
-        # calls crender_render_model)
-        self._ext.render_model(self._plan.value, tri, col, nrm, self._P_t, self.z_buffer, self.color_buffer,
-                               self.normals_buffer, self.winner_buffer, flags | self._extra_flags)
+        # calls crender_render_model; it returns the frame's number on the plan)
+        ticket = self._ext.render_model(self._plan.value, tri, col, nrm, self._P_t, self.z_buffer, self.color_buffer,
+                                        self.normals_buffer, self.winner_buffer, flags | self._extra_flags)
         self._last_flags = flags
         self._host_fresh = False
-        self._unverified = True
+        self._pending.append(_Frame(ticket, flags, self._inputs, self._order, self._inputs_private,
+                                    self._fused_light, self._inputs_stage))
 
     def _tile_coherent(self, inputs, private, generation=None):
         """Large models are kept in HBM in tile-coherent order: sorted, once per upload, by the
@@ -472,19 +520,76 @@ class AdvancedPixelBufferFiller:
         return sorted_inputs, order
 
     def _check_bins(self):
-        """Synchronise; if the last frame overflowed its bin lists, grow them and redo it.
-        Re-rendering is exact: the result is a per-pixel minimum over the prior value and
-        all fragments, so fragments that already landed change nothing."""
-        self._checking = True
+        """Synchronise the stream; if a pending frame overflowed its bin lists, grow them and redo it.
+        Returns True if a frame was rendered again (the buffers changed since the call began)."""
         self._redone = False
+        self._settle(block=True)
+        return self._redone
+
+    def _poll(self, frame):
+        """None while the frame's usage record has not landed, else (entries needed, capacity)."""
+        need, cap = C.c_int64(), C.c_int64()
+        rc = self._lib.crender_plan_poll_bin_usage(self._plan, frame.ticket, C.byref(need), C.byref(cap))
+        if rc == _capi.EBUSY:
+            return None
+        _capi.check(rc, "crender_plan_poll_bin_usage")
+        return need.value, cap.value
+
+    def _settle(self, block):
+        """Verify the pending frames, oldest first, from the records their raster launches left in the
+        plan's pinned host memory (crender_plan_poll_bin_usage: no copy, no event).  block=False:
+        stop at the first frame whose record has not landed; block=True: synchronise the stream
+        first (once), so that every record has.  A frame that overflowed its bin lists is rendered
+        again — with every frame after it, in order: re-rendering is exact, the result is a
+        per-pixel minimum over the prior value and all fragments in which a later frame wins equal
+        depths, so fragments that already landed change nothing and the replayed sequence restores
+        who wins a tie."""
+        if self._checking:
+            return
+        self._checking = True
         try:
-            self._check_bins_locked()
+            synced = False
+            if block:
+                self._settle_pipe()
+                torch.cuda.current_stream(self.device).synchronize()
+                synced = True
+            while self._pending:
+                got = self._poll(self._pending[0])
+                if got is None:
+                    if not block:
+                        return
+                    if synced:      # (launched on another stream than today's current one)
+                        torch.cuda.synchronize(self.device)
+                        got = self._poll(self._pending[0])
+                        if got is None:
+                            raise _capi.CrenderError("a finished frame left no bin-usage record")
+                    continue
+                need, cap = got
+                if need <= cap:
+                    self._pending.pop(0)
+                    continue
+                # overflow: grow, then replay this frame and everything launched on top of it
+                frames, self._pending = self._pending, []
+                if self._lib.crender_plan_last_frame_direct(self._plan) and not (self._extra_flags & _capi.NO_DIRECT_BINS):
+                    # this scene does not fit the small-scene direct bins: general path from now on
+                    self._extra_flags |= _capi.NO_DIRECT_BINS
+                else:
+                    self._bin_floor = max(self._bin_floor, int(need * 1.25) + 1024)
+                    self._ensure_plan(max(f.inputs[0].shape[0] for f in frames), capacity=self._bin_floor)
+                keep = (self._inputs, self._order, self._inputs_private, self._fused_light, self._inputs_stage)
+                for f in frames:
+                    self._inputs, self._order, self._inputs_private, self._fused_light, self._inputs_stage = \
+                        f.inputs, f.order, f.private, f.light, f.stage
+                    self._submit(f.flags)
+                self._inputs, self._order, self._inputs_private, self._fused_light, self._inputs_stage = keep
+                self._redone = True
+                block = True
+                torch.cuda.current_stream(self.device).synchronize()
+                synced = True
         finally:
             self._checking = False
-        self._unverified = False
-        return self._redone              # True: a frame was rendered again (buffers changed since)
 
-    def _check_bins_locked(self):
+    def _settle_pipe(self):
         if self._pipe is not None and self._pipe.n > 0:
             need = self._pipe.overflow(self)
             if need:
@@ -500,25 +605,10 @@ class AdvancedPixelBufferFiller:
                 self._pipe.close()
                 self._pipe = None
                 self._redone = True
-                self._launch(_capi.FUSED_CLEAR)
+                self._pending.clear()
+                self._submit(_capi.FUSED_CLEAR)
             else:
                 self._pipe.n = 0
-        if not self._plan or self._inputs is None:
-            torch.cuda.current_stream(self.device).synchronize()
-            return
-        need, cap = C.c_int64(), C.c_int64()
-        _capi.check(self._lib.crender_plan_last_bin_usage(self._plan, self._stream(), C.byref(need),
-                                                          C.byref(cap)), "crender_plan_last_bin_usage")
-        if need.value > cap.value:
-            if self._lib.crender_plan_last_frame_direct(self._plan):
-                # this scene does not fit the small-scene direct bins: general path from now on
-                self._extra_flags |= _capi.NO_DIRECT_BINS
-            else:
-                self._bin_floor = max(self._bin_floor, int(need.value * 1.25) + 1024)
-                self._ensure_plan(self._inputs[0].shape[0], capacity=self._bin_floor)
-            self._redone = True
-            self._launch(self._last_flags)
-            self._check_bins_locked()
 
     # ------------------------------------------------------------- reference API --
     def get_size(self):
@@ -535,6 +625,7 @@ class AdvancedPixelBufferFiller:
         generation = getattr(model, "generation", None)
         key = tuple((id(a), getattr(a, "shape", None)) for a in src) + (generation,)
         private = not any(isinstance(a, torch.Tensor) for a in src)
+        self._upload_stage = None
         if refresh or not self.cache_inputs or key != self._input_key:
             inputs = self._upload(src, ("model._vertices_by_triangles", "model._colors_by_triangles",
                                         "model._normals_by_triangles"), composite=not clear)
@@ -546,7 +637,8 @@ class AdvancedPixelBufferFiller:
             self._host_exposed = False
         else:
             self._push_host_edits()
-        self._launch(_capi.FUSED_CLEAR if clear else 0, inputs, private=private, generation=generation)
+        self._launch(_capi.FUSED_CLEAR if clear else 0, inputs, private=private, generation=generation,
+                     stage=self._upload_stage)
         if self._host and refresh_views:
             # arrays handed out earlier are views of the reference's own buffers there: they show
             # this render too
@@ -566,28 +658,41 @@ class AdvancedPixelBufferFiller:
         if not (arrs[0].shape == arrs[1].shape == arrs[2].shape):
             raise ValueError("vertex, colour and normal arrays must have the same shape")
         T = arrs[0].shape[0]
-        # The device side of the staging buffer is what the previous frame was rendered from:
-        # frames still in flight on the swap chain's streams must be done with it, and a frame
-        # whose bin lists have not been verified must be (it would be redone from these tensors).
         self._join_pipe()
-        if self._unverified and composite:
-            self._check_bins()
-        if self._stage is None or self._stage[0].shape[1] != T:
-            with torch.cuda.device(self.device):
-                self._stage = (torch.empty((3, T, 3, 3), dtype=torch.float32, pin_memory=True),
-                               torch.empty((3, T, 3, 3), dtype=torch.float32, device=self.device))
-            self._stage_np = self._stage[0].numpy()
-            self._stage_done = None
-        if self._stage_done is not None:
-            self._stage_done.synchronize()          # the last copy out of the host buffer has been read
+        st = self._free_stage(T, composite)
         for k in range(3):
-            np.copyto(self._stage_np[k], arrs[k])
-        pin, dev = self._stage
+            np.copyto(st.host[k], arrs[k])
         with torch.cuda.device(self.device):
-            dev.copy_(pin, non_blocking=True)
-            self._stage_done = torch.cuda.Event()
-            self._stage_done.record(torch.cuda.current_stream(self.device))
-        return (dev[0], dev[1], dev[2])
+            st.dev.copy_(st.pin, non_blocking=True)
+            st.done.record(torch.cuda.current_stream(self.device))
+        st.busy = True
+        self._upload_stage = st
+        return (st.dev[0], st.dev[1], st.dev[2])
+
+    def _free_stage(self, T, composite):
+        """A staging slot for T triangles that may be overwritten now: its last copy has left the
+        host, and no pending frame this one composites on still needs its device side for a redo.
+        (Frames in flight that merely READ the device side are ordered before the new copy by the
+        stream.)  Another slot is made only when none is free — a caller that renders faster than the
+        GPU — up to four for small models, two for large ones; with all taken, the pending frames are
+        waited for (back-pressure: the one place where this path synchronises)."""
+        if composite and self._pending:
+            self._settle(block=False)                    # frames whose records have landed need nothing any more
+        for attempt in range(2):
+            held = {id(f.stage) for f in self._pending} if composite else set()
+            for st in self._stages:
+                if id(st) in held or (st.busy and not st.done.query()):
+                    continue
+                st.busy = False
+                if st.cap < T:
+                    self._stages[self._stages.index(st)] = st = _Stage(T, self.device)
+                return st.shape(T)
+            if len(self._stages) < (4 if T * 108 <= (8 << 20) else 2):
+                self._stages.append(_Stage(T, self.device))
+                return self._stages[-1].shape(T)
+            self._check_bins()                           # synchronises: every copy has left, every frame is verified
+        st = self._stages[0] = _Stage(T, self.device)    # (not reached: after a synchronisation every slot is free)
+        return st.shape(T)
 
     # north_star wording; the reference's method is render_model
     render = render_model
@@ -605,6 +710,7 @@ class AdvancedPixelBufferFiller:
     def render_arrays(self, tri, col, nrm, clear=False):
         """``render_model`` on explicit [T,3,3] float32 arrays (numpy or torch, any device).
         ``clear=True`` renders into freshly initialised buffers in the same pass."""
+        self._upload_stage = None
         inputs = self._upload((tri, col, nrm), ("tri", "col", "nrm"), composite=not clear)
         self._input_key = None
         if clear:
@@ -612,7 +718,8 @@ class AdvancedPixelBufferFiller:
         else:
             self._push_host_edits()
         self._launch(_capi.FUSED_CLEAR if clear else 0, inputs,
-                     private=not any(isinstance(a, torch.Tensor) for a in (tri, col, nrm)))
+                     private=not any(isinstance(a, torch.Tensor) for a in (tri, col, nrm)),
+                     stage=self._upload_stage)
 
     def set_fused_illumination(self, light_direction=None):
         """Fuse ``GuroIllumination(light_direction).draw_illumination`` into every frame that starts
@@ -674,7 +781,9 @@ class AdvancedPixelBufferFiller:
                                                  self._stream()), "crender_raster")
         self._last_flags = _capi.FUSED_CLEAR       # (a redo after a bin overflow projects the resident
         self._host_fresh = False                   #  vertices itself: the same pixels)
-        self._unverified = True
+        self._pending.clear()
+        self._pending.append(_Frame(self._lib.crender_plan_frame_ticket(self._plan), _capi.FUSED_CLEAR, self._inputs,
+                                    None, self._inputs_private, self._fused_light, self._inputs_stage))
 
     def clear(self):
         """Back to the state __cinit__ leaves (.pyx:65-67)."""
@@ -684,6 +793,7 @@ class AdvancedPixelBufferFiller:
                                                 self.normals_buffer.data_ptr(), self._win_ptr(),
                                                 self.h, self.w, self.y0, self.y1, self._stream()),
                         "crender_clear")
+        self._pending.clear()          # (whatever those frames dropped is gone with the rest)
         self._host_fresh = False
         self._host_exposed = False
 

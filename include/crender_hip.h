@@ -36,14 +36,15 @@
 extern "C" {
 #endif
 
-#define CRENDER_ABI_VERSION 4
+#define CRENDER_ABI_VERSION 5
 #define CRENDER_API __attribute__((visibility("default")))
 
 enum {
     CRENDER_OK = 0,
     CRENDER_EINVAL = 1,  /* bad argument (null pointer, negative size, bad strip) */
     CRENDER_EHIP = 2,    /* HIP runtime error; text in crender_last_error()       */
-    CRENDER_ENOMEM = 3   /* workspace smaller than crender_plan_workspace_bytes   */
+    CRENDER_ENOMEM = 3,  /* workspace smaller than crender_plan_workspace_bytes   */
+    CRENDER_EBUSY = 4    /* crender_plan_poll_bin_usage: that frame's record has not landed yet */
 };
 
 /* flags of crender_raster / crender_render_model / crender_raster_atomic */
@@ -130,6 +131,23 @@ CRENDER_API int crender_plan_last_bin_usage(crender_plan *plan, void *stream,
                                 int64_t *needed, int64_t *capacity);
 
 CRENDER_API int crender_plan_last_frame_direct(crender_plan *plan);
+
+/* The same figures WITHOUT a host round trip, per frame (no reference counterpart: the reference's
+ * render_model, .pyx:92-104, returns when the buffers are written; a caller of this library that wants
+ * to return before the GPU is done needs to learn of a dropped frame afterwards).  Every raster launch
+ * on a plan (crender_raster / crender_render_model / crender_draw / a pipeline's frames) is numbered,
+ * from 1, and leaves its figures in pinned host memory the plan owns, written by the launch itself —
+ * no copy command, no event.
+ *   crender_plan_frame_ticket    number of the most recent raster launch on the plan (0: none yet)
+ *   crender_plan_poll_bin_usage  CRENDER_OK and the figures of frame `ticket` (as crender_plan_last_bin_usage
+ *                                reports them, with the same switch of an overflowed direct-bin plan to
+ *                                the general path) once its record has landed; CRENDER_EBUSY while it
+ *                                has not — nothing is waited for, nothing is enqueued; CRENDER_EINVAL
+ *                                for a frame never launched or older than the last 8.
+ * Once `stream` of that launch has been synchronised by any means the record is there. */
+CRENDER_API uint64_t crender_plan_frame_ticket(crender_plan *plan);
+CRENDER_API int crender_plan_poll_bin_usage(crender_plan *plan, uint64_t ticket, int64_t *needed,
+                                            int64_t *capacity);
 
 /* Tile-coherent triangle order (no reference counterpart: a data-layout choice for scenes of
  * millions of small triangles, where gathering unsorted 36-byte records dominates the frame).

@@ -1498,6 +1498,118 @@ def test_views_cross_pcie_only_when_handed_out(oracle):
     assert_bit_equal(filler.get_normals_buffer(), f.normals_buffer, "strided numpy input")
 
 
+def test_composite_renders_never_wait_for_the_gpu(oracle, monkeypatch):
+    """render_model(model) — the call Renderer.render makes (cy/renderer.py:47) — from numpy arrays, 50
+    times on top of each other with no getter in between: the bin lists of every frame are verified
+    from the records the raster launches leave in pinned host memory (crender_plan_poll_bin_usage),
+    so the loop never asks crender_plan_last_bin_usage (a device-to-host copy and a stream
+    synchronisation per call, round 4) and synchronises at most for back-pressure — when the host has
+    run four frames ahead of the GPU and every staging slot is taken — never per call; the pixels are
+    the oracle's."""
+    import torch
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    H = W = 512
+    models = [scene("trex_inputs.npz"), scene("cube_inputs.npz")]
+    # (the second model nearer and smaller each time round, so that later frames win and lose pixels)
+    filler = AdvancedPixelBufferFiller(H, W, fov=45, track_winner=True)
+    filler.render_model(_M(*models[0]))
+    filler.synchronize()                                 # plans, staging buffers: set-up is over
+    filler.clear()
+    calls = {"last_bin_usage": 0, "sync": 0, "poll": 0}
+    lib = filler._lib
+    real_usage, real_poll = lib.crender_plan_last_bin_usage, lib.crender_plan_poll_bin_usage
+
+    def counted(name, fn):
+        def wrapper(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return wrapper
+    monkeypatch.setattr(lib, "crender_plan_last_bin_usage", counted("last_bin_usage", real_usage))
+    monkeypatch.setattr(lib, "crender_plan_poll_bin_usage", counted("poll", real_poll))
+    monkeypatch.setattr(torch.cuda.Stream, "synchronize", counted("sync", torch.cuda.Stream.synchronize))
+    monkeypatch.setattr(torch.cuda.Event, "synchronize", counted("sync", torch.cuda.Event.synchronize))
+    monkeypatch.setattr(torch.cuda, "synchronize", counted("sync", torch.cuda.synchronize))
+    f = oracle.OracleFiller(H, W, fov=45)
+    rng = np.random.default_rng(5)
+    frames = []
+    for i in range(50):
+        tri, col, nrm = models[i % 2]
+        tri = tri * np.float32(1.0 - 0.004 * (i // 2)) + rng.uniform(-0.02, 0.02, 3).astype(np.float32)
+        frames.append((tri.astype(np.float32), col, nrm))
+    for tri, col, nrm in frames:
+        filler.render_model(_M(tri, col, nrm))
+    assert calls["last_bin_usage"] == 0 and calls["sync"] <= len(frames) // 3, calls
+    assert calls["poll"] >= 1 and len(filler._pending) <= 6
+    monkeypatch.undo()
+    for tri, col, nrm in frames:
+        f.render_arrays(tri, col, nrm)
+    assert_bit_equal(filler.get_z_buffer(), f.z_buffer, "z after 50 composite renders")
+    assert_bit_equal(filler.get_color_buffer(), f.color_buffer, "colour")
+    assert_bit_equal(filler.get_normals_buffer(), f.normals_buffer, "normal")
+    assert_bit_equal(filler.get_winner_tensor().cpu().numpy(), f.winner, "winner")
+    assert not filler._pending
+
+
+def test_overflow_found_late_replays_the_sequence_in_order(oracle):
+    """Four composite renders from numpy arrays with no getter in between, the FIRST of which
+    overflows its direct bins, and later ones that hold triangles at exactly the depths of earlier
+    ones (the later call must win the tie, .pyx:223): whenever the overflow is noticed — at the
+    second call if the first frame's record has landed by then, at the getter otherwise — the frames
+    from the overflowed one on are rendered again from their own inputs, in order."""
+    from cython3dmodelrenderer_amd import _capi
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    rng = np.random.default_rng(29)
+    t1, c1, n1 = random_soup(rng, 6000, 512, size_px=(2, 6), frac_backface=0.0, margin=-0.97)
+    t2, c2, n2 = scene("cube_inputs.npz")
+    t2 = np.concatenate([t2, t1[:700]]); c2 = np.concatenate([c2, c1[:700] * 0.5]); n2 = np.concatenate([n2, n1[:700]])
+    t3, c3, n3 = t1[300:1200].copy(), c1[300:1200] * 0.25, n1[300:1200].copy()
+    t4, c4, n4 = scene("trex_inputs.npz")
+    t4 = np.concatenate([t4, t1[600:900]]); c4 = np.concatenate([c4, c1[600:900] * 0.125]); n4 = np.concatenate([n4, n1[600:900]])
+    seq = [(t1, c1, n1), (t2, c2, n2), (t3, c3, n3), (t4, c4, n4)]
+    f = oracle.OracleFiller(512, 512, fov=45)
+    for a in seq:
+        f.render_arrays(*a)
+    filler = AdvancedPixelBufferFiller(512, 512, fov=45, tile=32, track_winner=True)
+    for a in seq:
+        filler.render_model(_M(*a))
+    assert_bit_equal(filler.get_z_buffer(), f.z_buffer, "z")
+    assert_bit_equal(filler.get_color_buffer(), f.color_buffer, "colour")
+    assert_bit_equal(filler.get_normals_buffer(), f.normals_buffer, "normal")
+    assert_bit_equal(filler.get_winner_tensor().cpu().numpy(), f.winner, "winner")
+    assert filler._extra_flags & _capi.NO_DIRECT_BINS, "the first frame was meant to overflow the direct bins"
+
+
+def test_poll_bin_usage_c_abi(hip):
+    """crender_plan_frame_ticket / crender_plan_poll_bin_usage: tickets count raster launches from 1,
+    a record lands with its frame (after a synchronisation it is there), reports what
+    crender_plan_last_bin_usage reports, and frames older than the ring are refused."""
+    import ctypes as C
+    import torch
+    from cython3dmodelrenderer_amd import _capi
+    lib = _capi.load()
+    rng = np.random.default_rng(31)
+    tri, col, nrm = random_soup(rng, 400, 256, size_px=(30, 90), frac_backface=0.0)
+    P = hip.projection_matrix(45.0, 0.1, 1000.0, 256, 256)
+    fb = hip.FrameBuffers(256, 256)
+    t, c, n = _dev(tri), _dev(col), _dev(nrm)
+    plan = hip.Plan(256, 256, len(tri), tile=32, bin_capacity=300)
+    need, cap = C.c_int64(), C.c_int64()
+    assert lib.crender_plan_frame_ticket(plan.handle) == 0
+    assert lib.crender_plan_poll_bin_usage(plan.handle, 1, C.byref(need), C.byref(cap)) == _capi.EINVAL
+    for k in range(1, 12):
+        hip.render_model(plan, t, c, n, P, fb, clear=True, direct_bins=(k % 2 == 0))
+        assert lib.crender_plan_frame_ticket(plan.handle) == k
+    torch.cuda.synchronize()
+    want = plan.bin_usage()                       # frame 11: scan path, 300 entries are too few
+    assert want[0] > want[1] == 300
+    assert lib.crender_plan_poll_bin_usage(plan.handle, 11, C.byref(need), C.byref(cap)) == _capi.OK
+    assert (need.value, cap.value) == want
+    assert lib.crender_plan_poll_bin_usage(plan.handle, 10, C.byref(need), C.byref(cap)) == _capi.OK
+    assert need.value <= cap.value and cap.value != 300          # frame 10 went through the direct bins
+    assert lib.crender_plan_poll_bin_usage(plan.handle, 3, C.byref(need), C.byref(cap)) == _capi.EINVAL
+    assert lib.crender_plan_poll_bin_usage(plan.handle, 12, C.byref(need), C.byref(cap)) == _capi.EINVAL
+
+
 def _plain_f32_vertex_normals(vertices, faces):
     """model.py:175-208 with every operation spelled out (no BLAS call): what the device kernels
     compute, on the host.  A dot of two float32 3-vectors = float32 products summed in float64 and
