@@ -38,12 +38,12 @@ import time
 
 # The CPU baseline's OpenMP threads stay where they start, one per physical core, neighbours first
 # (a 256-CPU host otherwise migrates sixteen threads across its CCDs between frames: 16 threads were
-# 1.9x one thread in round 3, and the figure moved 30 % from box to box).  libgomp reads these once,
-# when it is loaded — torch brings a copy — so they are set before anything else is imported.
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
-# (the CPUs this process may use, taken NOW: once libgomp is loaded it pins the main thread to the first
-# core, and the mask read later would say "two CPUs")
+# 1.9x one thread in round 3, and the figure moved 30 % from box to box).  libgomp reads OMP_PROC_BIND /
+# OMP_PLACES once, when it is loaded, and then binds the thread that loaded it to the first place — so
+# the baseline runs in a CHILD process of its own that gets the two variables (the oracle needs no
+# GPU), and this process, whose main thread submits every frame, is never bound (under
+# torch.distributed.run every rank would otherwise sit on the same core).
+OMP_BINDING = {"OMP_PROC_BIND": "close", "OMP_PLACES": "cores"}
 try:
     _ALLOWED_CPUS = sorted(os.sched_getaffinity(0))
 except AttributeError:
@@ -61,26 +61,36 @@ def algorithmic_bytes(T, rows, W):
     return 108 * T + 28 * rows * W
 
 
-def load_traffic(workload):
-    """HBM bytes per raster launch from the committed PMC profile, if one exists."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def csrc_sha16():
+    """Fingerprint of what the kernels are built from (cython3dmodelrenderer_amd/_build.py)."""
+    from cython3dmodelrenderer_amd import _build
+    return _build.source_sha16()
+
+
+def _profiled(name, workload):
+    """The workload's entry of a committed profile summary (profiles/<name>) — only if that summary was
+    made from the kernel sources this run is built from (its "csrc_sha16", stamped at profiling time
+    by scripts/make_*_json.py): a figure measured on other kernels says nothing about this run."""
     try:
-        with open(path) as fh:
-            return json.load(fh).get(workload, {}).get("raster_hbm_bytes_per_launch")
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            doc = json.load(fh)
     except Exception:
-        return None
+        return {}
+    if doc.get("csrc_sha16") != csrc_sha16():
+        return {}
+    return doc.get(workload, {})
+
+
+def load_traffic(workload):
+    """HBM bytes per raster launch from the committed PMC profile, if one exists for these kernels."""
+    return _profiled("traffic.json", workload).get("raster_hbm_bytes_per_launch")
 
 
 def load_rocprof_avg_ms(workload, kernel):
     """Average launch duration (ms) of `kernel` in the committed rocprofv3 kernel trace of this
     workload's bench command (profiles/kernel_avg.json, made by scripts/summarize_prof.py), if any."""
-    path = os.path.join(ROOT, "profiles", "kernel_avg.json")
-    try:
-        with open(path) as fh:
-            ns = json.load(fh).get(workload, {}).get(kernel)
-        return None if ns is None else float(ns) * 1e-6
-    except Exception:
-        return None
+    ns = _profiled("kernel_avg.json", workload).get(kernel)
+    return None if ns is None else float(ns) * 1e-6
 
 
 def cpu_model():
@@ -117,14 +127,39 @@ def host_topology():
     return len(allowed), (len(cores) or None)
 
 
-def cpu_baseline(tri, col, nrm, H, W, fov, budget_s=16.0, passes=3):
-    """Version-C-shaped CPU oracle on this host's cores, same frame definition (SURVEY.md section
-    8d): thread counts 1, 8, 16 — the README's columns (/root/reference/README.md:76) — and every
-    CPU the process may use; best of `passes` passes each after a warm-up frame, threads bound to
-    cores (see the top of this file).  The headline figure is 16 threads (the README's best column
-    and north_star's denominator).  Bounded: about `budget_s` seconds in all."""
+def cgroup_cpu_quota():
+    """CPUs' worth of time this process's cgroup may use (cpu.max), or None if unlimited / unknown."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if quota != "max":
+            return max(1, int(float(quota) / float(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())             # cgroup v1
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0 and period > 0:
+            return max(1, quota // period)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def _cpu_child(spec):
+    """Runs in the CPU-only child process (bench.py --cpu-child): the Version-C-shaped CPU oracle on this
+    host's cores, same frame definition (SURVEY.md section 8d) — thread counts 1, 8, 16 (the README's
+    columns, /root/reference/README.md:76) and one thread per physical core the process may use
+    (capped by the cgroup's CPU quota: more threads than that only measure the throttle); best of
+    `passes` passes each after a warm-up frame, threads bound to cores.  With `api` also the oracle's
+    side of the api_call block.  Prints one JSON object."""
+    from cython3dmodelrenderer_amd import scenes
     from oracle import oracle as O
+    tri, col, nrm, (H, W), fov = scenes.scene(spec["workload"], synth_T=spec["synth_T"])
+    if spec["max_triangles"] >= 0:
+        tri, col, nrm = (a[:spec["max_triangles"]] for a in (tri, col, nrm))
+    budget_s, passes = spec["budget_s"], spec["passes"]
     ncpu, ncores = host_topology()
+    quota = cgroup_cpu_quota()
 
     def measure(threads, budget):
         f = O.OracleFiller(H, W, fov=fov, n_threads=threads, mode="omp")
@@ -147,8 +182,9 @@ def cpu_baseline(tri, col, nrm, H, W, fov, budget_s=16.0, passes=3):
         return best, n
 
     counts = [t for t in (1, 8, 16) if t <= ncpu]
-    if ncpu not in counts:
-        counts.append(ncpu)
+    every = min(ncores or ncpu, quota or ncpu)   # one thread per physical core, within the quota
+    if every not in counts and every > 1:
+        counts.append(every)
     head = 16 if 16 in counts else counts[-1]
     by_threads, frames = {}, {}
     for t in counts:
@@ -156,13 +192,60 @@ def cpu_baseline(tri, col, nrm, H, W, fov, budget_s=16.0, passes=3):
         by_threads[str(t)] = 1.0 / dt
         frames[str(t)] = n
     dt = 1.0 / by_threads[str(head)]
-    return {"value": 1.0 / dt, "unit": "frames/s", "cores": head, "kind": "port",
-            "ms_per_frame": dt * 1e3, "host_cpus": ncpu, "host_physical_cores": ncores, "cpu_model": cpu_model(),
-            "frames_per_s_by_threads": by_threads,
-            "speedup_over_one_thread": {k: v / by_threads["1"] for k, v in by_threads.items()} if "1" in by_threads else None,
-            "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
-            "sample": f"best of {passes} passes of {frames[str(head)]} full frames of the same workload (clear + project + "
-                      f"raster) per thread count, OpenMP dynamic schedule + per-pixel locks, threads bound to cores"}
+    best_t = max(by_threads, key=lambda k: by_threads[k])
+    out = {"value": 1.0 / dt, "unit": "frames/s", "cores": head, "kind": "port",
+           "ms_per_frame": dt * 1e3,
+           "best": {"threads": int(best_t), "frames_per_s": by_threads[best_t]},
+           "host_cpus": ncpu, "host_physical_cores": ncores, "cgroup_cpu_quota": quota, "cpu_model": cpu_model(),
+           "frames_per_s_by_threads": by_threads,
+           "speedup_over_one_thread": {k: v / by_threads["1"] for k, v in by_threads.items()} if "1" in by_threads else None,
+           "omp": {k: os.environ.get(k) for k in OMP_BINDING},
+           "process": "CPU-only child of bench.py (the OpenMP binding is confined to it)",
+           "sample": f"best of {passes} passes of {frames[str(head)]} full frames of the same workload (clear + project + "
+                     f"raster) per thread count, OpenMP dynamic schedule + per-pixel locks, threads bound to cores"}
+    res = {"cpu_baseline": out}
+    if spec.get("api"):
+        # the oracle's side of the api_call block: the reference's own calls on min(16, ncpu) threads
+        from cython3dmodelrenderer_amd.illumination import GuroIllumination
+        m = _Model(tri, col, nrm)
+        light = GuroIllumination([0, 0, 1])
+        threads = min(16, ncpu)
+        of = O.OracleFiller(H, W, fov=fov, n_threads=threads, mode="omp")
+
+        def cpu_render():
+            of.render_model(m)
+            light.draw_illumination(of.color_buffer, of.normals_buffer)
+            return of.color_buffer
+        res["api_cpu_oracle"] = {"threads": threads,
+                                 "render_model_ms": _timed(lambda: of.render_model(m), lambda: None, 1.5),
+                                 "renderer_render_ms": _timed(cpu_render, lambda: None, 1.5)}
+    print(json.dumps(res), flush=True)
+
+
+def cpu_baseline(workload, synth_T, max_triangles, api=False, budget_s=16.0, passes=3):
+    """cpu_baseline (and the oracle's half of api_call) from the CPU-only child process."""
+    import subprocess
+    spec = {"workload": workload, "synth_T": synth_T, "max_triangles": max_triangles, "api": bool(api),
+            "budget_s": budget_s, "passes": passes}
+    env = dict(os.environ)
+    for k, v in OMP_BINDING.items():
+        env.setdefault(k, v)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", json.dumps(spec)],
+                       env=env, stdout=subprocess.PIPE, check=True, text=True)
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def _timed(call, sync, budget):
+    call(); call(); sync()                  # warm-up: plans, pinned buffers, staging
+    t0 = time.perf_counter()
+    call(); sync()
+    one = time.perf_counter() - t0
+    n = int(max(3, min(200, budget / max(one, 1e-5))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        call()
+    sync()
+    return (time.perf_counter() - t0) / n * 1e3
 
 
 class _Model:
@@ -178,26 +261,16 @@ def api_calls(tri, col, nrm, H, W, fov, device, budget_s=3.0):
       render_model(model)                       .pyx:92-104 (upload + K1 + K2, buffers composite)
       render_model(model); get_color_buffer()   .pyx:249 on top
       Renderer.render(model)                    cy/renderer.py:47-49 with GuroIllumination
-    each beside the CPU oracle's same call sequence on min(16, ncpu) threads."""
+    (the CPU oracle's same call sequences on min(16, ncpu) threads come from the CPU child process)."""
     import torch
     from cython3dmodelrenderer_amd import Renderer
     from cython3dmodelrenderer_amd.illumination import GuroIllumination
     from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
-    from oracle import oracle as O
     m = _Model(tri, col, nrm)
     light = GuroIllumination([0, 0, 1])
 
     def timed(call, sync, budget=budget_s):
-        call(); call(); sync()                  # warm-up: plans, pinned buffers, staging
-        t0 = time.perf_counter()
-        call(); sync()
-        one = time.perf_counter() - t0
-        n = int(max(3, min(200, budget / max(one, 1e-5))))
-        t0 = time.perf_counter()
-        for _ in range(n):
-            call()
-        sync()
-        return (time.perf_counter() - t0) / n * 1e3
+        return _timed(call, sync, budget)
 
     def dsync():
         torch.cuda.synchronize(device)
@@ -205,6 +278,9 @@ def api_calls(tri, col, nrm, H, W, fov, device, budget_s=3.0):
     out = {"unit": "ms per call", "model_arrays": "host numpy, uploaded by every call (as the reference copies them)"}
     f = AdvancedPixelBufferFiller(H, W, fov=fov, device=device)
     out["render_model_ms"] = timed(lambda: f.render_model(m), dsync)
+    # the same call when the caller waits for the GPU after each one (what a caller that reads the
+    # buffers right away sees; the figure above is the rate of calls that only enqueue)
+    out["render_model_then_wait_ms"] = timed(lambda: (f.render_model(m), dsync()), lambda: None)
     out["render_model_plus_color_ms"] = timed(lambda: (f.render_model(m), f.get_color_buffer()), dsync)
     f3 = AdvancedPixelBufferFiller(H, W, fov=fov, device=device)
     out["render_model_plus_three_buffers_ms"] = timed(
@@ -212,17 +288,6 @@ def api_calls(tri, col, nrm, H, W, fov, device, budget_s=3.0):
     for name, mode in (("numpy_illumination", False), ("default", None), ("on_device", True), ("fused", "fused")):
         r = Renderer(AdvancedPixelBufferFiller(H, W, fov=fov, device=device), light, None, H, W, on_device=mode)
         out[f"renderer_render_{name}_ms"] = timed(lambda: r.render(m), dsync)
-    threads = min(16, os.cpu_count() or 1)
-    of = O.OracleFiller(H, W, fov=fov, n_threads=threads, mode="omp")
-    cpu = {"threads": threads}
-    cpu["render_model_ms"] = timed(lambda: of.render_model(m), lambda: None, budget_s / 2)
-
-    def cpu_render():
-        of.render_model(m)
-        light.draw_illumination(of.color_buffer, of.normals_buffer)
-        return of.color_buffer
-    cpu["renderer_render_ms"] = timed(cpu_render, lambda: None, budget_s / 2)
-    out["cpu_oracle"] = cpu
     return out
 
 
@@ -272,7 +337,10 @@ def main():
     ap.add_argument("--chunks", type=int, default=1,
                     help="strips: sub-strips per rank, each exchanged on a second stream while the "
                          "next one is rasterized")
+    ap.add_argument("--cpu-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_child:
+        return _cpu_child(json.loads(args.cpu_child))
 
     # more hardware queues than the runtime's default of 4, so that four streams of the swap
     # chain plus torch's own do not share one (read by the HIP runtime when it starts)
@@ -452,12 +520,19 @@ def main():
                            "(no exchange: the frame is complete in its memory)"}
         del solo
 
+    # CPUs the thread that submits the frames may run on, NOW (after torch / libgomp are loaded): a
+    # runtime that bound it would show here — smallest over the ranks
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
     if world > 1:
         t = torch.tensor([elapsed, raster_ms, bin_ms, elapsed_render_only or 0.0, kframe_events_ms or 0.0,
-                          kframe_b2b_ms or 0.0], dtype=torch.float64,
+                          kframe_b2b_ms or 0.0, -float(affinity)], dtype=torch.float64,
                          device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, raster_ms, bin_ms, ero, ke, kb = (float(v) for v in t.cpu())
+        elapsed, raster_ms, bin_ms, ero, ke, kb, naff = (float(v) for v in t.cpu())
+        affinity = int(-naff)
         if elapsed_render_only is not None:
             elapsed_render_only = ero
         if lookahead:
@@ -546,7 +621,30 @@ def main():
                          # launch was not profiled
                          "traffic": load_traffic(args.workload) if rows == H else None},
             "bin_entries": {"needed": need, "capacity": cap},
+            # the kernels' sources; profiles/*.json figures are quoted only if they were measured on these
+            "csrc_sha16": csrc_sha16(),
+            "submit_thread_affinity_cpus_min_over_ranks": affinity,
         }
+        if strips:
+            # what the exchange moves and what it costs: the line explains its own scaling
+            step_ms = elapsed / args.steps * 1e3
+            bare_ms = elapsed_render_only / args.steps * 1e3
+            gathered = not args.no_gather
+            out["exchange"] = {
+                "kind": args.exchange if gathered else None,
+                "exchange_bytes_received_per_rank": D.exchange_bytes_received(args.exchange, H, W, world, 0) if gathered else 0,
+                "exchange_ms": step_ms - bare_ms,
+                "ms_per_step": step_ms, "ms_per_step_without_exchange": bare_ms,
+                "bytes_received_per_rank_by_choice": {k: D.exchange_bytes_received(k, H, W, world, 0) for k in D.EXCHANGES},
+                "projection_broadcast_bytes_per_rank": 36 * T if args.project == "broadcast" else 0,
+                "expectation": ("DESIGN.md section 5: with exchange = planes every rank receives 28 B/pixel x (N-1)/N "
+                                "of the frame over xGMI, several times the time ONE GPU needs to render the whole "
+                                "frame — a speed-up below 1x is the predicted outcome of north_star's layout; "
+                                "'present' moves 9x less"),
+            }
+            out["config"]["multi_gpu"] += ("; predicted by DESIGN.md section 5 to be SLOWER than one GPU with exchange = "
+                                           "planes (the exchange, not the rasterization, bounds the sharded frame)"
+                                           if args.exchange == "planes" and gathered else "")
         if one_gpu is not None:
             one_gpu["speedup_of_this_line"] = fps / one_gpu["value"]
             out["strong_scaling_reference"] = one_gpu
@@ -555,12 +653,24 @@ def main():
                 "sorted ONCE at upload into tile-coherent order (Morton code of the 32-pixel tile of each "
                 "triangle's projected centroid: key kernel + device radix sort + three gathers, about 1 GB of "
                 "traffic, ~2 ms, outside the timed region); depth ties and the winner plane keep the caller's indices")
+        want_api = not args.no_api_calls and world == 1 and H * W <= 4096 * 4096 and T <= 1_000_000
+        child = None
         if not args.no_cpu_baseline:
             # (rank 0, beside every N: the other ranks wait at the closing barrier meanwhile)
-            out["cpu_baseline"] = cpu_baseline(tri, col, nrm, H, W, fov)
-            out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
-        if not args.no_api_calls and world == 1 and H * W <= 4096 * 4096 and T <= 1_000_000:
+            child = cpu_baseline(args.workload, args.synth_triangles, args.max_triangles, api=want_api)
+            cb = out["cpu_baseline"] = child["cpu_baseline"]
+            # north_star's denominator is the 16-thread column; the best column is beside it
+            out["speedup_vs_cpu_baseline"] = fps / cb["value"]
+            out["speedup_vs_best_cpu_column"] = fps / cb["best"]["frames_per_s"]
+            lone = 1e3 / (elapsed_single / args.steps * 1e3)       # frames/s of frames one at a time on one stream
+            out["speedup_lone_frame"] = {"frames_per_s": lone, "vs_16_threads": lone / cb["value"],
+                                         "vs_best_cpu_column": lone / cb["best"]["frames_per_s"],
+                                         "what": "ms_per_frame_single_stream (no frames in flight together) "
+                                                 "against the CPU columns"}
+        if want_api:
             out["api_call"] = api_calls(tri, col, nrm, H, W, fov, device)
+            if child is not None and "api_cpu_oracle" in child:
+                out["api_call"]["cpu_oracle"] = child["api_cpu_oracle"]
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -45,6 +45,19 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the HIP library cannot be built")
 
 
+def source_sha16() -> str:
+    """Fingerprint of everything the kernels are built from — the translation units, their headers and
+    the compiler flags: profiles/*.json carry it from profiling time, and bench.py quotes a committed
+    profile figure only when it matches the sources it runs."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(SRC_DIR, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read() + b"\0")
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
@@ -73,10 +86,18 @@ def compile_library(out: str, extra_flags=(), sources=None, src_dir: str = SRC_D
 
         with ThreadPoolExecutor(max_workers=min(4, len(sources))) as pool:
             list(pool.map(one, zip(sources, objs)))
-        cmd = [_hipcc()] + LINK_FLAGS + ["-o", out] + objs
+        # link beside the target and rename onto it: ranks started together on a stale library all
+        # build, and none may dlopen a half-written file
+        part = f"{out}.{os.getpid()}.part"
+        cmd = [_hipcc()] + LINK_FLAGS + ["-o", part] + objs
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd, stderr=err)
+        try:
+            subprocess.check_call(cmd, stderr=err)
+            os.replace(part, out)
+        finally:
+            if os.path.exists(part):
+                os.remove(part)
     return out
 
 

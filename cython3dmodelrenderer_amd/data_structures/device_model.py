@@ -207,6 +207,13 @@ class DeviceModel:
         self._gather(self._normals, self._triangles_normals, self._normals_by_triangles)
         self._update()
 
+    def touch(self):
+        """Tell whoever keeps a snapshot of the by-triangle arrays (a filler's tile-coherent copy)
+        that they were rewritten behind this class's back — a write through ``data_ptr()``, a kernel
+        of the caller's.  Every method of this class that rewrites them does the same: ``generation``
+        is part of the contract between a model and ``AdvancedPixelBufferFiller``."""
+        self.generation += 1
+
     def get_mean_vertex(self):
         return self._fetch_stats()[:3].copy()
 

@@ -180,6 +180,24 @@ def all_gather_substrips(planes, H: int, rank: int, world: int, chunk: int, chun
 
 EXCHANGES = ("planes", "color", "present")
 PROJECTIONS = ("local", "broadcast")
+EXCHANGE_BYTES_PER_PIXEL = {"planes": 28, "color": 12, "present": 3}
+
+
+def exchange_bytes_received(exchange: str, H: int, W: int, world: int, rank: int) -> int:
+    """Bytes rank `rank` receives per frame under `exchange`: every other rank's rows of the payload."""
+    y0, y1 = strip_rows(H, world, rank)
+    return EXCHANGE_BYTES_PER_PIXEL[exchange] * (H - (y1 - y0)) * W
+
+
+def gather_present(gatherer, image, H: int, rank: int, world: int, chunk=None, chunks: int = 1):
+    """Exchange of the presented image (uint8 [H, W, 3], rows flipped as run.py:26 writes them): colour
+    rows [y0, y1) of a rank's strip (or of its sub-strip `chunk`) are image rows [H - y1, H - y0), so
+    the blocks come in DESCENDING row order and land through the staging tensors."""
+    def rows_of(r):
+        y0, y1 = strip_rows(H, world, r) if chunk is None else substrip_rows(H, world, r, chunk, chunks)
+        return H - y1, H - y0
+    block = strip_height(H, world) if chunk is None else chunk_height(H, world, chunks)
+    gatherer.gather_blocks(image, rank, world, block, rows_of)
 
 
 class StripRenderer:
@@ -337,11 +355,4 @@ class StripRenderer:
         return self._payload(self.filler)
 
     def _gather_present(self, chunk=None):
-        # the image is flipped (run.py:26): colour rows [y0, y1) are image rows [h - y1, h - y0)
-        H, world = self.h, self.world
-
-        def rows_of(r):
-            y0, y1 = strip_rows(H, world, r) if chunk is None else substrip_rows(H, world, r, chunk, self.chunks)
-            return H - y1, H - y0
-        block = strip_height(H, world) if chunk is None else chunk_height(H, world, self.chunks)
-        self._gather.gather_blocks(self.image, self.rank, world, block, rows_of)
+        gather_present(self._gather, self.image, self.h, self.rank, self.world, chunk, self.chunks)

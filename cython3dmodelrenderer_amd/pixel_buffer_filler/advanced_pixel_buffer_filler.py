@@ -39,6 +39,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -304,6 +305,8 @@ class AdvancedPixelBufferFiller:
         self._host_exposed = False     # a mirror was handed out and may have been edited
         self._stages = []              # numpy inputs' way up: up to two _Stage (pinned + device [3, T, 3, 3])
         self._inputs_stage = None      # the staging slot the resident inputs live in, if any
+        self._model_ref = None         # weak reference to a generation-counting model behind the resident inputs,
+        self._model_generation = None  # and the generation the resident (possibly sorted) copy was taken at
         self._sort_cache = None        # (key of caller-owned tensors, sorted inputs, order)
         self._pending = []             # frames launched whose bin lists have not been verified, oldest first
         self._redone = False
@@ -639,6 +642,11 @@ class AdvancedPixelBufferFiller:
             self._push_host_edits()
         self._launch(_capi.FUSED_CLEAR if clear else 0, inputs, private=private, generation=generation,
                      stage=self._upload_stage)
+        try:
+            self._model_ref = weakref.ref(model) if generation is not None else None
+        except TypeError:
+            self._model_ref = None
+        self._model_generation = generation
         if self._host and refresh_views:
             # arrays handed out earlier are views of the reference's own buffers there: they show
             # this render too
@@ -738,7 +746,29 @@ class AdvancedPixelBufferFiller:
         render_model / render_arrays call.  With ``pipeline=True`` (constructor) the filler is
         a swap chain of ``pipeline_depth`` (3 or 4 by default): consecutive frames render into
         rotating framebuffer sets on as many streams and overlap on the GPU; the buffer
-        attributes and getters always refer to the most recently submitted frame."""
+        attributes and getters always refer to the most recently submitted frame.
+
+        What "resident" means: device tensors handed in by the caller are read in place, every frame,
+        as they are then.  A model of 2^18 triangles or more (or ``presort=True``) is rendered from a
+        tile-coherent snapshot instead: for a model that counts its rewrites (``DeviceModel.generation``
+        — part of that class's contract: every method that rewrites the by-triangle arrays bumps it, and
+        so must anybody who writes them through ``data_ptr()``) the snapshot is retaken here when the
+        count has moved; bare tensors under ``presort=True`` keep the snapshot of the last
+        ``render_model`` / ``render_arrays`` call."""
+        model = self._model_ref() if self._model_ref is not None else None
+        if model is not None and self._order is not None and model.generation != self._model_generation:
+            # The resident copy is a tile-coherent SNAPSHOT of a model that has rewritten its arrays
+            # since (DeviceModel.shift / rotate / scale count their rewrites in `generation`): take a new
+            # one.  (Without a snapshot — small models, presort=False — the kernels read the model's
+            # own arrays and see every change anyway.)
+            self._join_pipe()
+            src = (model._vertices_by_triangles, model._colors_by_triangles, model._normals_by_triangles)
+            inputs = self._upload(src, ("model._vertices_by_triangles", "model._colors_by_triangles",
+                                        "model._normals_by_triangles"), composite=False)
+            self._inputs, self._order = self._tile_coherent(inputs, False, model.generation)
+            self._inputs_private = self._order is not None
+            self._inputs_stage = None
+            self._model_generation = model.generation
         use_pipe = self._pipeline if pipelined is None else (pipelined and self._pipeline)
         if not use_pipe:
             self._launch(_capi.FUSED_CLEAR)      # (joins the pipeline first if frames are pending)

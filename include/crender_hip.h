@@ -328,10 +328,13 @@ CRENDER_API int crender_present_u8(const float *d_color, unsigned char *d_out, i
  *                         (d_offsets int32 [V + 1], d_occurrences int32 [3 T]: per vertex the faces of
  *                         its (face, corner) occurrences, ascending; d_taken: 3 T bytes of scratch).
  *                         d_faces int32 [T][3] with non-negative indices.
- * numpy takes np.linalg.norm / np.dot / matmul from its BLAS build.  For the 3-vectors of this path
- * that is: float32 products added in a double accumulator and rounded once (OpenBLAS sdot), a
- * three-term float64 sum for the rotation — spelled out as such in the kernels, and bit-identical
+ * numpy takes np.linalg.norm / np.dot / matmul from its BLAS build, so "what the reference computes"
+ * is a property of that build, not of numpy.  The kernels match numpy built on OpenBLAS (verified:
+ * scipy-openblas 0.3.29, x86-64): float32 products added in a double accumulator and rounded once
+ * (its sdot's tail loop), a three-term float64 sum for the rotation — spelled out as such, and bit-identical
  * to the host Model on every mesh of tests/test_hip_parity_gpu.py::test_device_model_rotate_and_normals
+ * under that build (tests/test_host_cpu.py::test_numpy_dot_of_3_vectors guards the assumption; on
+ * another BLAS parity of this row is unpinned and the GPU test falls back to a bounded check)
  * (the de-duplication test `dot >= 1` is discontinuous: a 1-ulp difference in the dot would change
  * which face normals a vertex averages, as rounds 1-3's plain float32 sum did on 0.8 % of T-Rex's
  * vertices). */

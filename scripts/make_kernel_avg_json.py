@@ -39,5 +39,8 @@ for wl in ("trex1024", "bunny4096", "trex8192", "synth10m", "cube256"):
     if e:
         e["source"] = "rocprofv3 --kernel-trace --stats of bench.py (scripts/profile_gpu.sh), ns"
         out[wl] = e
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cython3dmodelrenderer_amd import _build  # noqa: E402
+out["csrc_sha16"] = _build.source_sha16()       # the kernels these figures were measured on (bench.py checks it)
 json.dump(out, open("profiles/kernel_avg.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

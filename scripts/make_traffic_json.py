@@ -21,5 +21,8 @@ for wl in ("trex1024", "bunny4096", "trex8192", "synth10m"):
                "raster_write_bytes": write,
                "raster_hbm_bytes_per_launch": 2 * fetch_raw + write,
                "source": f"{path} (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)"}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cython3dmodelrenderer_amd import _build  # noqa: E402
+out["csrc_sha16"] = _build.source_sha16()       # the kernels these figures were measured on (bench.py checks it)
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

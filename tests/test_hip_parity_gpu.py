@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from util import assert_bit_equal, random_soup, sha
+from util import assert_bit_equal, numpy_dot3_is_double_accumulated, random_soup, sha
 
 pytestmark = pytest.mark.gpu
 
@@ -1462,6 +1462,23 @@ def test_presorted_filler_follows_a_device_model_through_its_transforms(oracle, 
         assert_bit_equal(filler.get_z_buffer(), ref.z_buffer, f"step {step} z")
         assert_bit_equal(filler.get_color_buffer(), ref.color_buffer, f"step {step} colour")
         assert_bit_equal(filler.get_normals_buffer(), ref.normals_buffer, f"step {step} normal")
+    # render_frame() on the resident model: with a snapshot (presort) it has to be retaken when the model
+    # has counted a rewrite since; without one the kernels read the model's own arrays
+    for pipelined in (False, True):
+        f2 = AdvancedPixelBufferFiller(512, 512, fov=45, presort=presort, pipeline=pipelined)
+        f2.render_model(dm, clear=True)
+        for move in ([0.03, -0.04, 0.0], [0.0, 0.05, 0.05]):
+            dm.shift(move)
+            host.shift(move)
+            f2.render_frame()
+            f2.render_frame()
+            ref = oracle.OracleFiller(512, 512, fov=45)
+            ref.render_model(host)
+            assert_bit_equal(f2.get_z_buffer(), ref.z_buffer, f"render_frame after a shift (pipelined: {pipelined}) z")
+            assert_bit_equal(f2.get_color_buffer(), ref.color_buffer, "colour")
+        gen = dm.generation
+        dm.touch()
+        assert dm.generation == gen + 1
 
 
 def test_views_cross_pcie_only_when_handed_out(oracle):
@@ -1694,8 +1711,14 @@ def test_device_model_rotate_and_normals():
             print(f"{name} {angles}: {n_vdiff} of {len(dv)} vertices and {n_ndiff} vertex normals differ in bits, "
                   f"{flipped} de-duplication decisions fell the other way, max error {err.max():.2e}")
             assert n_vdiff <= max(2, len(dv) // 1000), name
-            assert flipped == 0, (name, flipped)
-            assert n_ndiff == 0, (name, n_ndiff)
+            if numpy_dot3_is_double_accumulated():
+                assert flipped == 0, (name, flipped)
+                assert n_ndiff == 0, (name, n_ndiff)
+            else:
+                # another BLAS behind this numpy (tests/test_host_cpu.py::test_numpy_dot_of_3_vectors fails
+                # first): bit parity with the host Model is unpinned, the de-duplication may flip on a
+                # 1-ulp difference of the dot — bounded as in rounds 1-3
+                assert flipped <= max(2, len(dv) // 50), (name, flipped)
             assert_bit_equal(dev._normals_by_triangles.cpu().numpy(), dn[fcs], f"{name}: normals by triangles")
             assert_bit_equal(dev._vertices_by_triangles.cpu().numpy(), dv[fcs], f"{name}: vertices by triangles")
             # keep the two models in step for the next rotation
@@ -1720,6 +1743,9 @@ def test_device_model_trex_from_the_mesh_to_the_golden_pixels(golden):
     with np.load(os.path.join(GOLDEN_DIR, "trex_mesh.npz")) as z:
         vertices, faces = z["vertices"], z["faces"]
     tri, col, nrm = load_fixture("trex_inputs.npz")
+    if not numpy_dot3_is_double_accumulated():
+        pytest.skip("this numpy's BLAS does not add float32 products in double: the device normals are pinned "
+                    "against scipy-openblas 0.3.29's sdot only (parity unpinned here)")
     dm = DeviceModel(Model(vertices, faces))
     dm.rotate([-90, 180, 0])
     dm.rotate([10, -80, 0])
@@ -1738,6 +1764,55 @@ def test_device_model_trex_from_the_mesh_to_the_golden_pixels(golden):
     assert sha(filler.get_normals_buffer()) == g["n"]
     filler.synchronize()
     assert sha(filler.get_winner_tensor().cpu().numpy()) == g["winner"]
+
+
+@pytest.mark.parametrize("on_device_model", [False, True])
+def test_renderer_normalize_model_fit(oracle, on_device_model):
+    """Renderer.render(model, normalize_model=True) — the reference's fit of the model into the image
+    (cy/renderer.py:40-46: scale by min(centre) / max span about the mean vertex, then shift the mean
+    to (h // 2, w // 2, -min(centre))) — on the host Model and on the DeviceModel, against the oracle
+    fed with the fit evaluated in numpy, statement by statement, right here."""
+    from cython3dmodelrenderer_amd import Renderer
+    from cython3dmodelrenderer_amd.data_structures import DeviceModel, Model
+    from cython3dmodelrenderer_amd.illumination import GuroIllumination
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    from cython3dmodelrenderer_amd.scenes import GOLDEN_DIR
+    with np.load(os.path.join(GOLDEN_DIR, "trex_mesh.npz")) as z:
+        vertices, faces = z["vertices"], z["faces"]
+    H, W = 192, 256
+    host = Model(vertices, faces)
+    host.set_uniform_color((40.0, 180.0, 250.0))
+    # ---- the fit in numpy (renderer.py:41-46 over model.py:153-160, 213-236)
+    v = np.array(vertices, dtype=np.float32)
+    mean = v.mean(axis=0)
+    span = np.max(np.linalg.norm(v - mean, axis=-1))
+    centre = (H // 2, W // 2)
+    image_span = min(centre)
+    coef = image_span / span
+    v -= mean; v *= coef; v += mean                                   # Model.scale, keep_position
+    mean = v.astype("float32").mean(axis=0)                            # _update_vertices_and_normals
+    v = (v + (-mean + [centre[0], centre[1], -image_span])).astype("float32")     # Model.shift
+    tri = v[faces]
+    nrm = host._normals_by_triangles.copy()                            # (unchanged by scale and shift)
+    col = host._colors_by_triangles.copy()
+    # (the fit puts the model at z = -min(centre), in pixel units — behind the reference's own camera;
+    # a wide field of view keeps part of it on screen: 1 207 pixels)
+    f = oracle.OracleFiller(H, W, fov=120)
+    f.render_arrays(tri, col, nrm)
+    oracle.guro(f.color_buffer, f.normals_buffer, [0.2, 0.1, 1])
+    assert int((f.z_buffer < 1e6).sum()) > 1000, "part of the fitted model is on screen"
+
+    model = host
+    if on_device_model:
+        model = DeviceModel(host)
+        model.set_uniform_color((40.0, 180.0, 250.0))
+    r = Renderer(AdvancedPixelBufferFiller(H, W, fov=120), GuroIllumination([0.2, 0.1, 1]), None, H, W)
+    img = r.render(model, normalize_model=True)
+    got_tri = model._vertices_by_triangles
+    got_tri = got_tri.cpu().numpy() if on_device_model else got_tri
+    assert_bit_equal(got_tri, tri, "fitted vertices by triangles")
+    assert_bit_equal(img, f.color_buffer, "shaded colour of the fitted model")
+    assert_bit_equal(r.pixel_buffer_filler.get_z_buffer(), f.z_buffer, "z of the fitted model")
 
 
 def test_device_model_stats_are_lazy():
@@ -1893,7 +1968,16 @@ def test_bench_launch_contract_two_ranks_strips():
         assert key in d, key
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["kind"] == "port" and "1" in cb["frames_per_s_by_threads"]
-    assert len(cb["frames_per_s_by_threads"]) >= min(4, 1 + sum(t <= cb["host_cpus"] for t in (8, 16)) + 1) - 1
+    assert len(cb["frames_per_s_by_threads"]) >= 1 + sum(t <= cb["host_cpus"] for t in (8, 16))
+    assert cb["best"]["frames_per_s"] == max(cb["frames_per_s_by_threads"].values())
+    assert cb["omp"]["OMP_PROC_BIND"] == "close"           # in the baseline's own process, and only there:
+    assert d["submit_thread_affinity_cpus_min_over_ranks"] > 2, "a rank's submitting thread was bound to a core"
+    ex = d["exchange"]                                      # the line explains its own scaling
+    assert ex["kind"] is None and ex["exchange_bytes_received_per_rank"] == 0          # (--no-gather)
+    assert ex["bytes_received_per_rank_by_choice"] == {"planes": 28 * 4096 * 8192, "color": 12 * 4096 * 8192,
+                                                       "present": 3 * 4096 * 8192}
+    assert abs(ex["exchange_ms"] - (d["ms_per_step"] - d["ms_per_step_without_exchange"])) < 1e-9
+    assert "speedup_lone_frame" in d and d["csrc_sha16"]
 
 
 @pytest.mark.gpu
@@ -1904,6 +1988,8 @@ def test_bench_launch_contract_two_ranks_frames():
                      "--warmup", "2", "--no-api-calls"], 2)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["workload"] == "trex1024"
     assert d["value"] > 0 and "cpu_baseline" in d and "roofline" in d
+    assert d["submit_thread_affinity_cpus_min_over_ranks"] > 2, "a rank's submitting thread was bound to a core"
+    assert "exchange" not in d and d["speedup_vs_best_cpu_column"] <= d["speedup_vs_cpu_baseline"] * 1.0000001
 
 
 @pytest.mark.gpu

@@ -318,6 +318,105 @@ def test_three_rank_ragged_substrips_gloo(tmp_path):
         assert f"rank {r} ok" in out
 
 
+_EIGHT_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from cython3dmodelrenderer_amd import distributed as D
+from cython3dmodelrenderer_amd import scenes
+from oracle import oracle as O
+world = 8
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=world)
+rank = dist.get_rank()
+torch.set_num_threads(1)
+tri, col, nrm = scenes.load_fixture("trex_inputs.npz")
+# the SCALE run's shape in small: eight equal strips (H a multiple of 8), every exchange choice, through
+# the calls StripRenderer.render_frame makes (the oracle stands in for the GPU filler).  Equal strips
+# of CPU tensors take Gatherer.gather_blocks' in-place branch — what RCCL runs on device tensors
+H, W = 64, 48
+y0, y1 = D.strip_rows(H, world, rank)
+assert y1 - y0 == 8
+f = O.OracleFiller(H, W, fov=45)
+f.render_arrays(tri, col, nrm, y0=y0, y1=y1)
+full = O.OracleFiller(H, W, fov=45)
+full.render_arrays(tri, col, nrm)
+g = D.Gatherer(None)
+taken = []
+real = dist.all_gather_into_tensor
+def spy(out, inp, group=None):
+    taken.append(out.data_ptr())
+    return real(out, inp, group=group)
+dist.all_gather_into_tensor = spy
+rows = lambda r: D.strip_rows(H, world, r)
+# exchange = planes: z, colour, normal in place
+planes = [torch.from_numpy(b.copy()) for b in (f.z_buffer, f.color_buffer, f.normals_buffer)]
+for p in planes:
+    g.gather_blocks(p, rank, world, D.strip_height(H, world), rows)
+assert taken == [p.data_ptr() for p in planes], "equal strips gather straight into the planes"
+for got, want in zip(planes, (full.z_buffer, full.color_buffer, full.normals_buffer)):
+    assert np.array_equal(got.numpy().view(np.uint32), want.view(np.uint32))
+# exchange = color
+c = torch.from_numpy(f.color_buffer.copy())
+g.gather_blocks(c, rank, world, D.strip_height(H, world), rows)
+assert np.array_equal(c.numpy().view(np.uint32), full.color_buffer.view(np.uint32))
+# exchange = present: the flipped uint8 image, blocks in descending row order (staged)
+image = torch.zeros((H, W, 3), dtype=torch.uint8)
+image[H - y1: H - y0] = torch.from_numpy(f.color_buffer[y0:y1][::-1].astype("uint8").copy())
+n_before = len(taken)
+D.gather_present(g, image, H, rank, world)
+assert taken[n_before] != image.data_ptr()
+assert np.array_equal(image.numpy(), full.color_buffer[::-1].astype("uint8"))
+assert D.exchange_bytes_received("planes", H, W, world, rank) == 28 * (H - 8) * W
+assert D.exchange_bytes_received("present", H, W, world, rank) == 3 * (H - 8) * W
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_eight_rank_equal_strips_every_exchange_gloo(tmp_path):
+    """world_size 8, eight equal strips — the shape of the driver's SCALE run — for planes / color /
+    present; the planes and colour exchanges must take the in-place branch of Gatherer.gather_blocks."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "eight_worker.py"
+    script.write_text(_EIGHT_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(8)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert f"rank {r} ok" in out
+
+
+def test_profile_figures_are_quoted_only_for_the_sources_they_were_measured_on(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic and committed rocprofv3 average come from profiles/*.json; they carry the
+    fingerprint of the kernel sources they were measured on and are dropped (null) for any other."""
+    import json
+    import bench
+    from cython3dmodelrenderer_amd import _build
+    sha = _build.source_sha16()
+    assert len(sha) == 16 and sha == bench.csrc_sha16()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    for stamp, want in ((sha, True), ("0" * 16, False), (None, False)):
+        doc_t = {"trex1024": {"raster_hbm_bytes_per_launch": 123.0}}
+        doc_k = {"trex1024": {"k_raster": 11000.0}}
+        if stamp is not None:
+            doc_t["csrc_sha16"] = doc_k["csrc_sha16"] = stamp
+        (prof / "traffic.json").write_text(json.dumps(doc_t))
+        (prof / "kernel_avg.json").write_text(json.dumps(doc_k))
+        assert bench.load_traffic("trex1024") == (123.0 if want else None)
+        assert bench.load_rocprof_avg_ms("trex1024", "k_raster") == (0.011 if want else None)
+    # the fingerprint follows the sources: one more byte in a translation unit changes it
+    monkeypatch.setattr(_build, "HIPCC_FLAGS", _build.HIPCC_FLAGS + ["-DX"])
+    assert _build.source_sha16() != sha
+
+
 def test_strip_rows_partition():
     from cython3dmodelrenderer_amd.distributed import strip_rows
     for H, n in [(8192, 8), (1024, 8), (1000, 3), (7, 8), (64, 1)]:

@@ -180,3 +180,44 @@ def test_oracle_guro_matches_numpy_statements(oracle):
         nan = np.isnan(want)
         assert (np.isnan(got) == nan).all()
         assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32)), light
+
+
+def test_back_face_test_divides_in_double(oracle, tmp_path):
+    """.pyx:202 culls on `(n0z + n1z + n2z) / 3 >= 0.0` with float operands and an int literal.  The
+    oracle (and the HIP `backface`) take the division to be a DOUBLE one — then the test equals
+    `sum >= 0` — which matters for exactly one input: a sum of -1.4e-45 (the smallest negative
+    denormal) divided by 3 in FLOAT would round to -0, and -0 >= 0 would cull the triangle.  No build
+    of the reference's filler exists here to decide it; what can be pinned is
+    what Cython emits for that very expression: this container's Cython, the one oracle/build_ref.sh
+    compiles the reference's math_utils.pyx with, turns a statement of the same shape (written here,
+    not the reference's text) into `... / 3.0) >= 0.0` — C's double division.  "Parity unpinned" for
+    any Cython that would emit something else."""
+    import re
+    import shutil
+    import subprocess
+    # 1. the oracle: the smallest negative denormal sum is drawn, +denormal / +0 / -0 sums are culled
+    tri = np.array([[[-0.3, -0.3, 1.0], [0.3, -0.3, 1.0], [0.0, 0.3, 1.0]]], np.float32)
+    col = np.full((1, 3, 3), 200.0, np.float32)
+    for zs, drawn in (([-1e-45, 0.0, 0.0], True), ([1e-45, -1e-45, -1e-45], True), ([1e-45, 0.0, 0.0], False),
+                      ([0.0, 0.0, 0.0], False), ([-0.0, -0.0, -0.0], False), ([-1e-45, 1e-45, 0.0], False)):
+        nrm = np.zeros((1, 3, 3), np.float32)
+        nrm[0, :, 2] = np.array(zs, np.float32)
+        f = oracle.OracleFiller(64, 64, fov=45)
+        f.render_arrays(tri, col, nrm)
+        assert bool((f.z_buffer < 1e6).any()) == drawn, zs
+    # 2. what Cython emits for an expression of that shape
+    cython = shutil.which("cython")
+    if cython is None:
+        pytest.skip("no cython here: the division's type stays unpinned")
+    (tmp_path / "snippet.pyx").write_text(
+        "# cython: language_level=3\n"
+        "cdef int faces_away(float[:, :, :] n, Py_ssize_t i) nogil:\n"
+        "    if (n[i, 0, 2] + n[i, 1, 2] + n[i, 2, 2]) / 3 >= 0.0:\n"
+        "        return 1\n"
+        "    return 0\n")
+    subprocess.check_call([cython, "snippet.pyx"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    c = (tmp_path / "snippet.c").read_text()
+    stmt = [l for l in c.splitlines() if ">= 0.0)" in l and "__pyx_v_n.data" in l]
+    assert len(stmt) == 1
+    assert re.search(r"\)\s*/\s*3\.0\)\s*>=\s*0\.0\)", stmt[0]), stmt[0][-80:]
+    assert "(float)3" not in stmt[0] and "3.0f" not in stmt[0]

@@ -41,3 +41,19 @@ def random_soup(rng, T, res, size_px=(1.0, 40.0), z=(0.5, 3.0), frac_backface=0.
     nrm[flip, :, 2] *= -1
     col = rng.uniform(0, 255, (T, 3, 3)).astype(np.float32)
     return tri, col, nrm
+
+
+def numpy_dot3_is_double_accumulated():
+    """True if this numpy's np.dot of float32 3-vectors is float32 products in a double accumulator,
+    rounded once (scipy-openblas 0.3.29's x86-64 sdot: what row f2's device kernels spell out).  The
+    bit-exact device-vs-host-Model checks of the vertex normals hold for such a numpy only; on any
+    other BLAS they are 'parity unpinned' and fall back to the bounded check."""
+    rng = np.random.default_rng(0)
+    n = 4000
+    a = rng.standard_normal((n, 3)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = a + rng.standard_normal((n, 3)).astype(np.float32) * np.float32(1e-4)
+    ref = np.array([np.dot(a[i], b[i]) for i in range(n)], dtype=np.float32)
+    p = a * b
+    mine = (p[:, 0].astype(np.float64) + p[:, 1].astype(np.float64) + p[:, 2].astype(np.float64)).astype(np.float32)
+    return bool(np.array_equal(mine.view(np.uint32), ref.view(np.uint32)))
