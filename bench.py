@@ -650,7 +650,7 @@ def main():
             out["strong_scaling_reference"] = one_gpu
         if args.workload == "synth10m":
             out["config"]["resident_model"] = (
-                "sorted ONCE at upload into tile-coherent order (Morton code of the 32-pixel tile of each "
+                "sorted ONCE at upload into tile-coherent order (Morton code of the 4-pixel cell of each "
                 "triangle's projected centroid: key kernel + device radix sort + three gathers, about 1 GB of "
                 "traffic, ~2 ms, outside the timed region); depth ties and the winner plane keep the caller's indices")
         want_api = not args.no_api_calls and world == 1 and H * W <= 4096 * 4096 and T <= 1_000_000

@@ -83,7 +83,8 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
     L.off_offs = o;    o = align_up(o + sizeof(uint32_t) * (size_t)(L.g.ntiles + 1));
     L.off_trange = o;  o = align_up(o + sizeof(uint2) * (size_t)max_T);
     L.off_proj = o;    o = align_up(o + sizeof(float) * 9 * (size_t)max_T);
-    L.off_entries = o; o = align_up(o + sizeof(uint32_t) * (size_t)cap);
+    // (8 bytes per list entry: with a triangle order the entries are (position, caller's index) pairs)
+    L.off_entries = o; o = align_up(o + sizeof(uint2) * (size_t)cap);
     L.off_direct = o;  o = align_up(o + sizeof(BinEntry) * (size_t)L.g.ntiles * (size_t)L.direct_cap);
     L.total = o;
     return true;

@@ -219,20 +219,32 @@ __global__ __launch_bounds__(kWave) void k_count_wave(const float *__restrict__ 
 // ranges, then offsets + returning atomics, then the entries: three memory round trips per wavefront,
 // 8 192 wavefronts resident — so a wavefront takes kFillPer x 64 triangles through each round trip
 // together (10 M triangles: 97 -> 78 us with two, 77 with four; profiles/r03/ab_fill_groups.txt).
+// PAIRS (a triangle order is set, crender_plan_set_triangle_order): an entry is the pair (position in
+// the arrays, caller's index) — the raster kernel keys its depth comparisons on the caller's index and
+// used to gather it per entry from orig_of: for the sixth of a tile's records that live in a
+// neighbouring tile's cluster that was a 128-byte line for 4 bytes (10 M triangles: 260 MB per frame).
+// Here orig_of is read as a stream, 4 bytes per triangle.
 constexpr int kFillPer = 2;
+template <bool PAIRS>
 __global__ __launch_bounds__(kWave) void k_fill_wave(const uint2 *__restrict__ trange,
                                                      const uint32_t *__restrict__ offs,
                                                      uint32_t *__restrict__ cursor,
                                                      uint32_t *__restrict__ entries,
+                                                     const uint32_t *__restrict__ orig_of,
                                                      uint32_t capacity, int64_t T, Geom G)
 {
     __shared__ uint32_t hist[kWaveHistTiles];
+    __shared__ uint32_t orig[PAIRS ? kWave * kFillPer : 1];     // the wavefront's caller's indices (any lane writes any owner's entry)
+    uint2 *const pairs = reinterpret_cast<uint2 *>(entries);
     const int lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * (kWave * kFillPer);
     uint2 r[kFillPer];
 #pragma unroll
-    for (int p = 0; p < kFillPer; ++p)
-        r[p] = (b0 + p * kWave + lane < T) ? trange[b0 + p * kWave + lane] : make_uint2(kNoTiles, 0);
+    for (int p = 0; p < kFillPer; ++p) {
+        const bool in = b0 + p * kWave + lane < T;
+        r[p] = in ? trange[b0 + p * kWave + lane] : make_uint2(kNoTiles, 0);
+        if constexpr (PAIRS) orig[p * kWave + lane] = in ? orig_of[b0 + p * kWave + lane] : 0u;
+    }
 #pragma unroll
     for (int i = 0; i < kWaveHistTiles / kWave; ++i) hist[i * kWave + lane] = 0;   // (while the ranges are on their way)
     int X0 = 0x7FFFFFFF, X1 = -1, Y0 = 0x7FFFFFFF, Y1 = -1;
@@ -245,17 +257,20 @@ __global__ __launch_bounds__(kWave) void k_fill_wave(const uint2 *__restrict__ t
     }
     wave_box(X0, X1, Y0, Y1);
     if (X1 < 0) return;
+    __syncthreads();        // histogram zeroed, the caller's indices in LDS
     const int bw = X1 - X0 + 1, area = bw * (Y1 - Y0 + 1);
     if (area > kWaveHistTiles) {
 #pragma unroll
         for (int p = 0; p < kFillPer; ++p)
-            for_each_tile(r[p], (uint32_t)(b0 + p * kWave + lane), G.ntx, [&](int tile, uint32_t id) {
+            for_each_tile(r[p], (uint32_t)(p * kWave + lane), G.ntx, [&](int tile, uint32_t local) {
                 const uint32_t pos = offs[tile] + atomicAdd(&cursor[tile], 1u);
-                if (pos < capacity) entries[pos] = id;
+                if (pos < capacity) {
+                    if constexpr (PAIRS) pairs[pos] = make_uint2((uint32_t)b0 + local, orig[local]);
+                    else entries[pos] = (uint32_t)b0 + local;
+                }
             });
         return;
     }
-    __syncthreads();
 #pragma unroll
     for (int p = 0; p < kFillPer; ++p)
         for_each_tile_xy(r[p], [&](int tx, int ty, int) { atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u); });
@@ -287,7 +302,10 @@ __global__ __launch_bounds__(kWave) void k_fill_wave(const uint2 *__restrict__ t
     for (int p = 0; p < kFillPer; ++p)
         for_each_tile_xy(r[p], [&](int tx, int ty, int owner) {
             const uint32_t pos = atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u);
-            if (pos < capacity) entries[pos] = (uint32_t)(b0 + p * kWave + owner);
+            if (pos < capacity) {
+                if constexpr (PAIRS) pairs[pos] = make_uint2((uint32_t)(b0 + p * kWave + owner), orig[p * kWave + owner]);
+                else entries[pos] = (uint32_t)(b0 + p * kWave + owner);
+            }
         });
 }
 
@@ -461,6 +479,7 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
     // triangles can be expected to share tiles — a mesh, or a large model kept in tile-coherent
     // order; a large triangle soup in arbitrary order keeps the block histograms.
     const bool wave_scan = (plan->orig_of != nullptr || T < kWaveScanBelow) && !(dbg & 4);
+    plan->last_frame_pairs = !direct && wave_scan && plan->orig_of != nullptr && T > 0;
     if (T > 0 && direct) {
         // direct bins: one wavefront per 64 triangles
         HeavyReg hv;
@@ -535,9 +554,13 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
                 if (attr != hipSuccess) return fail_hip(attr, "hipFuncSetAttribute(k_fill)");
             }
-            if (wave_scan)
-                hipLaunchKernelGGL(k_fill_wave, dim3((unsigned)((T + kWave * kFillPer - 1) / (kWave * kFillPer))), dim3(kWave), 0, s,
-                                   plan->trange(), plan->offs(), count, plan->entries(),
+            if (wave_scan && plan->orig_of)
+                hipLaunchKernelGGL((k_fill_wave<true>), dim3((unsigned)((T + kWave * kFillPer - 1) / (kWave * kFillPer))), dim3(kWave), 0, s,
+                                   plan->trange(), plan->offs(), count, plan->entries(), plan->orig_of,
+                                   (uint32_t)L.capacity, T, G);
+            else if (wave_scan)
+                hipLaunchKernelGGL((k_fill_wave<false>), dim3((unsigned)((T + kWave * kFillPer - 1) / (kWave * kFillPer))), dim3(kWave), 0, s,
+                                   plan->trange(), plan->offs(), count, plan->entries(), plan->orig_of,
                                    (uint32_t)L.capacity, T, G);
             else if (lds_hist)
                 hipLaunchKernelGGL((k_fill<true>), dim3((unsigned)nblk), dim3(kThreads), lds, s,

@@ -266,11 +266,18 @@ __global__ __launch_bounds__(kThreads) void k_model_texture_colors(const float *
     }
 }
 
-// Sort key of a triangle for the tile-coherent order: Morton code of the 32-pixel tile its
-// projected centroid falls in (an ordering heuristic only: nothing exact depends on it).
+// Sort key of a triangle for the tile-coherent order: Morton code of the 4-pixel CELL its projected
+// centroid falls in — hence of its 8-, 16-, 32- and 64-pixel tile too (a Morton code's prefixes are the
+// coarser cells') — an ordering heuristic only: nothing exact depends on it.  Cells finer than the
+// raster tile keep neighbours in the frame neighbours in memory WITHIN a tile as well: the records a
+// tile takes from its neighbours' clusters (the sixth of its list whose centroid lies across the border)
+// sit in the few cells along that border instead of anywhere in the cluster, and the winners of a
+// wavefront's two pixel rows in a few runs of records.  10 M small triangles at 4096^2, same box:
+// cells of 32 / 16 / 8 / 4 / 2 pixels -> 2 175 / 2 057 / 2 002 / 1 948 / 1 938 MB fetched per raster
+// launch, 0.602 / 0.581 / 0.563 / 0.560 / 0.558 ms (profiles/r05/ab_order_cell_synth10m.txt).
 __global__ __launch_bounds__(kThreads) void k_tile_order_keys(const float *__restrict__ tri, int64_t T,
                                                               ProjConst P, int W, int H,
-                                                              uint32_t *__restrict__ keys)
+                                                              uint32_t *__restrict__ keys, int cell_shift)
 {
     const int64_t stride = (int64_t)gridDim.x * kThreads;
     for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < T; t += stride) {
@@ -282,9 +289,9 @@ __global__ __launch_bounds__(kThreads) void k_tile_order_keys(const float *__res
         x = x < 0 ? 0 : (x >= W ? W - 1 : x);
         y = y < 0 ? 0 : (y >= H ? H - 1 : y);
         if (!(c[0] == c[0]) || !(c[1] == c[1])) x = y = 0;
-        uint32_t a = (uint32_t)x >> 5, b = (uint32_t)y >> 5, m = 0;
+        uint32_t a = (uint32_t)x >> cell_shift, b = (uint32_t)y >> cell_shift, m = 0;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) m |= ((a >> k) & 1u) << (2 * k) | ((b >> k) & 1u) << (2 * k + 1);
+        for (int k = 0; k < 15; ++k) m |= ((a >> k) & 1u) << (2 * k) | ((b >> k) & 1u) << (2 * k + 1);
         keys[t] = m;
     }
 }
@@ -323,8 +330,12 @@ int crender_tile_order_keys(const float *d_tri, int64_t T, const float *P16, int
     if (T < 0 || !P16 || w <= 0 || h <= 0 || (T > 0 && (!d_tri || !d_keys)))
         return fail(CRENDER_EINVAL, "crender_tile_order_keys: bad argument");
     if (T == 0) return CRENDER_OK;
+    int cell_shift = 2;      // 4-pixel cells
+#ifdef CRENDER_DEV_KNOBS
+    if (std::getenv("CRENDER_ORDER_CELL_SHIFT")) cell_shift = std::atoi(std::getenv("CRENDER_ORDER_CELL_SHIFT"));
+#endif
     hipLaunchKernelGGL(k_tile_order_keys, dim3(grid_for((size_t)T, 4096)), dim3(kThreads), 0,
-                       static_cast<hipStream_t>(stream), d_tri, T, make_proj(P16, w, h), w, h, d_keys);
+                       static_cast<hipStream_t>(stream), d_tri, T, make_proj(P16, w, h), w, h, d_keys, cell_shift);
     CR_LAUNCH_CHECK("k_tile_order_keys");
     return CRENDER_OK;
 }

@@ -48,6 +48,7 @@ struct crender_plan {
     int timed_frames = 0;
     bool direct_ok = true;        // cleared once a frame overflowed the direct bins
     bool last_frame_direct = false;
+    bool last_frame_pairs = false;    // its list entries are (position, caller's index) pairs (k_fill_wave<true>)
     int64_t last_T = -1;          // triangle count of the last bin pass (crender_draw must match)
     // The per-tile counters exist twice.  Frame f bins into parity f & 1 and its raster pass
     // zeroes the OTHER parity for frame f + 1, so no raster workgroup ever writes a counter that
@@ -85,6 +86,7 @@ struct crender_plan {
     uint2 *trange() const { return reinterpret_cast<uint2 *>(ws + L.off_trange); }
     float *proj() const { return reinterpret_cast<float *>(ws + L.off_proj); }
     uint32_t *entries() const { return reinterpret_cast<uint32_t *>(ws + L.off_entries); }
+    uint2 *entry_pairs() const { return reinterpret_cast<uint2 *>(ws + L.off_entries); }   // (with a triangle order)
 };
 
 // Swap chain of `depth` (crender_pipeline_*): frame i runs entirely on the pipeline's stream

@@ -49,6 +49,21 @@ CR_DEV int xcd_band_tile(int b, int n)
     return xcd * per + (xcd < rem ? xcd : rem) + k;
 }
 
+// Slot of tile-local pixel (dx, dy) in the LDS key plane.  On 32-pixel tiles a row of the plane (32 keys of
+// 8 bytes) is exactly one sweep of the 64 LDS banks, so lanes that work on the same columns of different
+// rows — the 16 lanes of a 4x4 block, the rows of one wide box, the lanes of a run-wise sweep that sit a
+// few items apart — would all meet in the same banks.  Each row's PAIRS of keys are therefore permuted by
+// the row number (x ^ 2 (y mod 16)): the same columns of up to 16 consecutive rows lie in 16 different
+// bank groups.
+template <int TS>
+CR_DEV int key_slot(int dx, int dy)
+{
+#ifndef CRENDER_NO_KEY_SWIZZLE
+    if constexpr (TS == 32) return dy * 32 + (dx ^ ((dy << 1) & 30));
+#endif
+    return dy * TS + dx;
+}
+
 // Lower an LDS depth key (order-independent: the final key is the minimum over all fragments).
 CR_DEV void lds_key_min(unsigned long long *slot, unsigned long long k)
 {
@@ -385,7 +400,8 @@ struct TileLists {
     const uint32_t *offs;       // scan path: list offsets into `entries`; null = direct bins
     const uint32_t *count;      // direct bins: list lengths of THIS frame (never written here)
     uint32_t *count_next;       // the other parity's counters: zeroed here for the next frame
-    const uint32_t *entries;    // scan path: triangle indices
+    const uint32_t *entries;    // scan path: triangle indices — or (`pairs`: a triangle order is set and the
+    int pairs;                  // lists were written by k_fill_wave<true>) (position, caller's index) pairs
     const float4 *bins;         // direct bins: [ntiles][capacity] entries (BinEntry, three pieces each)
     uint32_t capacity;
     uint32_t T;                 // triangle count: list entries >= T (stale workspace) are ignored
@@ -412,15 +428,24 @@ struct TileLists {
     uint32_t usage_seq;
 };
 
-// One record of a tile's list: projected vertices, triangle index, pixel box.  false = a stale
-// index (beyond the frame's triangle count): no work.
+// One record of a tile's list: projected vertices, triangle index AS THE CALLER KNOWS IT (what depth
+// keys and the winner plane speak), pixel box.  false = a stale index (beyond the frame's triangle
+// count): no work.
 CR_DEV bool load_record(const TileLists &L, const float *__restrict__ proj, const Geom &G, uint32_t idx,
                         uint32_t &id, TriXYZ &t, uint32_t &ebx, uint32_t &eby)
 {
     if (L.offs) {
-        id = L.entries[idx];
-        if (id >= L.T) return false;
-        t = load_tri(proj + (size_t)id * 9);
+        uint32_t at;                 // position in the arrays
+        if (L.pairs) {
+            const uint2 e = reinterpret_cast<const uint2 *>(L.entries)[idx];
+            at = e.x; id = e.y;
+            if (at >= L.T) return false;
+        } else {
+            at = id = L.entries[idx];
+            if (at >= L.T) return false;
+            if (L.orig_of) id = L.orig_of[at];
+        }
+        t = load_tri(proj + (size_t)at * 9);
         int xl, xr, yt, yb;
         pixel_box(t.x0, t.y0, t.x1, t.y1, t.x2, t.y2, G.W, G.H, xl, xr, yt, yb);
         ebx = (uint32_t)xl | ((uint32_t)xr << 16);
@@ -433,7 +458,9 @@ CR_DEV bool load_record(const TileLists &L, const float *__restrict__ proj, cons
     id = __float_as_uint(e2.y);
     ebx = __float_as_uint(e2.z);
     eby = __float_as_uint(e2.w);
-    return id < L.T;
+    if (id >= L.T) return false;
+    if (L.orig_of) id = L.orig_of[id];
+    return true;
 }
 
 // ---- dispatch order from the previous frame's coverage -------------------------------------
@@ -763,11 +790,22 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             }
         } else {
             tile = (dbg & 8) ? xcd_band_tile(m, G.ntiles) : m;
+            const bool super_map = (dbg & (1 << 27)) && (G.ntx & 7) == 0 && (G.nty & 7) == 0 && (G.ntiles & 511) == 0;
+            if (super_map) {
+                // (experiment) workgroup m runs on XCD m % 8: deal 8 x 8-tile blocks round-robin to the
+                // XCDs and walk each block's tiles one after another on its XCD, so that neighbouring
+                // tiles — which share the records along their common border — meet in one L2
+                const uint32_t xcd = (uint32_t)m & 7u, j = (uint32_t)m >> 3;
+                const uint32_t sidx = (j >> 6) * 8u + xcd, local = j & 63u;
+                const uint32_t SX = (uint32_t)G.ntx >> 3;
+                const uint32_t sy = sidx / SX, sx = sidx - sy * SX;
+                tile = (int)((sy * 8u + (local >> 3)) * (uint32_t)G.ntx + sx * 8u + (local & 7u));
+            }
             // Large grids: scatter the dispatch order (block b -> tile b * stride mod ntiles) so
             // that a band of covered tiles is spread over the whole launch instead of arriving
             // together (T-Rex 8192^2: 0.446 -> 0.402 ms).  Small grids are faster in raster order
             // (T-Rex 1024^2: 24.7 vs 29.1 us), so the scatter starts at 32768 tiles.
-            if ((G.ntiles >= 32768) != ((dbg & 256) != 0)) {
+            if (!super_map && (G.ntiles >= 32768) != ((dbg & 256) != 0)) {
                 // (b * stride) mod ntiles, the product below 2^48: quotient from a double multiply
                 // (exact product, at most one off after rounding), remainder fixed up
                 const unsigned long long P = (unsigned long long)m * (unsigned)G.tile_stride;
@@ -784,7 +822,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             // the whole dispatch while a third of the chip's workgroup slots stand free.  Rotating
             // row ty by 9 * ty columns walks every pair through every column (T-Rex 1024^2 raster
             // 24.0 -> 21.6 us; the larger frames gain 0-2 %).
-            if (!(dbg & 512)) {
+            if (!(dbg & 512) && !super_map) {
                 const int ty = G.ntx_magic ? (int)__umulhi((uint32_t)tile, G.ntx_magic) : tile / G.ntx;
                 const int t = tile - ty * G.ntx + 9 * ty;
                 const int tx = G.ntx_magic ? t - (int)__umulhi((uint32_t)t, G.ntx_magic) * G.ntx : t % G.ntx;
@@ -860,7 +898,6 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     TriXYZ cur_t{};
     bool cur_ok = tid < kBatch && beg + tid < end;
     if (cur_ok) cur_ok = load_record(L, proj, G, beg + tid, cur_id, cur_t, cur_bx, cur_by);
-    if (cur_ok && L.orig_of) cur_id = L.orig_of[cur_id];      // from here on: the caller's index
 
     // depth keys of the tile: the prior buffer value (or the cleared value) per pixel
     // (32-pixel tiles: once it is known that the tile is not the pixel owners', see below)
@@ -872,7 +909,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                 const int x = X0 + (p % TS), y = Y0 + (p / TS);
                 if (x < X1 && y < Y1) k = make_key(zord_prior(zb[(size_t)y * G.W + x]), KEY_LOW_PRIOR);
             }
-            key[p] = k;
+            key[key_slot<TS>(p % TS, p / TS)] = k;
         }
     };
     if constexpr (TS != 32) init_keys();
@@ -1009,7 +1046,6 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             const uint32_t nxt = base + kBatch + tid;
             cur_ok = tid < kBatch && nxt < end;
             if (cur_ok) cur_ok = load_record(L, proj, G, nxt, cur_id, cur_t, cur_bx, cur_by);
-            if (cur_ok && L.orig_of) cur_id = L.orig_of[cur_id];
             // Per-pixel sweep: every pixel of every clipped box is one work item; thread t takes
             // items t, t + 256, ...  All lanes work on a sample that lies in its box (a 4x4 block
             // of a small box is mostly empty: 71 % of T-Rex 1024^2's block lanes were inside their
@@ -1046,7 +1082,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                         const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
                         const int px0 = ((int)i - dy * bwn) * kItemPixels;
                         const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
-                        unsigned long long *kp = &key[(y - Y0) * TS + (x - X0)];
+                        unsigned long long *kp = &key[key_slot<TS>(x - X0, y - Y0)];
 #pragma unroll
                         for (int j = 0; j < kItemPixels; ++j) {
                             unsigned long long k;
@@ -1078,15 +1114,77 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                         const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
                         const int px0 = ((int)i - dy * bwn) * kItemPixels32;
                         const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
-                        unsigned long long *kp = &key[(y - Y0) * TS + (x - X0)];
 #pragma unroll
                         for (int j = 0; j < kItemPixels32; ++j) {
                             float n1, n2, n3;
                             numerators(st, x + j, y, n1, n2, n3);
                             unsigned long long k;
-                            if (fragment_from(st, id, n1, n2, n3, true, k) && (j == 0 || px0 + j < bw)) lds_key_min(kp + j, k);
+                            if (fragment_from(st, id, n1, n2, n3, true, k) && (j == 0 || px0 + j < bw))
+                                lds_key_min(&key[key_slot<TS>(x + j - X0, y - Y0)], k);
                         }
                     }
+                }
+            };
+            // The same items — pairs of x-neighbours of the clipped boxes' rows — in RUNS: thread t takes
+            // items [t c, (t + 1) c) of the batch (c = ceil(total / 256)), finds the record of its first
+            // item by the search above ONCE and then walks: next pair of the row, next row, next record.
+            // Per item that is no search (6 dependent LDS reads and ~55 of ~230 vector instructions on
+            // batches of more than 64 records) and no division for the row; the record is re-read
+            // from LDS per item as before (registers: the 32-pixel kernel has none to spare), one round
+            // trip.  Lanes of a wavefront hold neighbouring records (consecutive LDS banks), every lane
+            // makes the same number of trips.
+            auto sweep_runs = [&](const uint32_t *wo_, int total_) {
+                const int chunk = (total_ + kThreads - 1) / kThreads;
+                int e = tid * chunk;
+                int left = (e + chunk < total_ ? e + chunk : total_) - e;       // items of this thread's run
+                if (left <= 0) return;
+                uint32_t i;
+                int r = find_record(q.pre.px_scan, wo_, e, i);
+                int dy, px0;             // the item within its record: row of the box, first pixel of the pair
+                {
+                    const int bwn = (box_w(packed_wh(q.box[r])) + kItemPixels32 - 1) / kItemPixels32;
+                    dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
+                    px0 = ((int)i - dy * bwn) * kItemPixels32;
+                }
+                // ONE flat loop, its state stepped with selects: with `if (row done) { if (record done) ... }`
+                // the compiler turned the walk into three nested loops (pairs of a row, rows of a record,
+                // records) in which every lane waits for the wavefront's longest row and tallest box —
+                // twice the time.  A record without work (clipped away: rare) costs an idle trip.
+                while (left > 0) {
+                    const uint32_t pb = q.box[r];
+                    const uint32_t xy = packed_xy(pb, X0, Y0), wh = packed_wh(pb);
+                    const int bw = box_w(wh), bh = box_h(wh);
+                    const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r], q.x2[r], q.y2[r], q.z2[r]};
+                    const uint32_t id = q.tri[r];
+                    TriSetup st;
+                    {
+                        st.x0 = t.x0; st.y0 = t.y0; st.z0 = t.z0; st.x1 = t.x1; st.y1 = t.y1; st.z1 = t.z1;
+                        st.x2 = t.x2; st.y2 = t.y2; st.z2 = t.z2;
+                        st.l01 = t.x1 - t.x2; st.l02 = t.y1 - t.y2;
+                        st.l11 = t.x2 - t.x0; st.l12 = t.y2 - t.y0;
+                        st.l21 = t.x0 - t.x1; st.l22 = t.y0 - t.y1;
+                        st.l03 = q.pre.l03[r]; st.l13 = q.pre.l13[r]; st.l23 = q.pre.l23[r];
+                        st.r1 = q.pre.r1[r]; st.r2 = q.pre.r2[r]; st.r3 = q.pre.r3[r];
+                        st.fast = st.r1 != 0.0f;
+                        st.rej1 = st.rej2 = st.rej3 = 0.0f;
+                    }
+                    const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
+#pragma unroll
+                    for (int j = 0; j < kItemPixels32; ++j) {
+                        float n1, n2, n3;
+                        numerators(st, x + j, y, n1, n2, n3);
+                        unsigned long long k;
+                        if (fragment_from(st, id, n1, n2, n3, true, k) && px0 + j < bw)
+                            lds_key_min(&key[key_slot<TS>(x + j - X0, y - Y0)], k);
+                    }
+                    left -= bw != 0 ? 1 : 0;
+                    px0 += kItemPixels32;
+                    const bool row_done = px0 >= bw;
+                    px0 = row_done ? 0 : px0;
+                    dy += row_done ? 1 : 0;
+                    const bool rec_done = dy >= bh;
+                    dy = rec_done ? 0 : dy;
+                    r += rec_done ? 1 : 0;
                 }
             };
             if constexpr (TS == 32) {
@@ -1146,7 +1244,16 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                 wop[0] = 0;
 #pragma unroll
                 for (int w = 0; w < kThreads / 64; ++w) wop[w + 1] = wop[w] + q.wave_px[w];
-                sweep_pixels(q.pre.px_scan, wop, (int)wop[kThreads / 64]);
+                // (item by item — thread t takes items t, t + 256, ... with a search per item — only as a
+                // development knob: the run-wise walk is faster on every workload once the key plane is
+                // swizzled, T-Rex 1024^2 pipelined +12 %, 10 M small triangles' raster launch -4 %)
+                const int items = (int)wop[kThreads / 64];
+#ifdef CRENDER_RUNS_MAX_AVG
+                if ((dbg & (1 << 30)) || items > CRENDER_RUNS_MAX_AVG * nrec) sweep_pixels(q.pre.px_scan, wop, items); else
+#else
+                if (dbg & (1 << 30)) sweep_pixels(q.pre.px_scan, wop, items); else
+#endif
+                sweep_runs(wop, items);
             } else if (TS == 64 && ((total < 16 * nrec && !(dbg & 8192)) || (dbg & 128))) {
                 // Small records: each of the 16 lane groups takes one contiguous run of blocks,
                 // so a record is set up by (almost) one group only; tight loop, plain division.
@@ -1163,7 +1270,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                         const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
                         unsigned long long k;
                         if (x < wk.bx1 && y < wk.by1 && fragment(wk.s, wk.id, x, y, k))
-                            lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                            lds_key_min(&key[key_slot<TS>(x - X0, y - Y0)], k);
                         if (++p >= pend) break;
                         if (++b < wk.nblk) {
                             if (++bx == wk.nbx) { bx = 0; ++by; }
@@ -1224,7 +1331,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                             numerators(wk.s, x, y, n1, n2, n3);
                             unsigned long long k;
                             if (x < wk.bx1 && y < wk.by1 && fragment_from(wk.s, wk.id, n1, n2, n3, allow_fast, k))
-                                lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                                lds_key_min(&key[key_slot<TS>(x - X0, y - Y0)], k);
                             if (++p >= pend) break;   // (p < pend guarantees another survivor)
                             m &= m - 1;
                             if (m == 0) {
@@ -1255,7 +1362,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                             if (wave_any(live)) {   // wavefront-uniform
                                 unsigned long long k;
                                 if (live && fragment_from(wk.s, wk.id, n1, n2, n3, allow_fast, k))
-                                    lds_key_min(&key[(y - Y0) * TS + (x - X0)], k);
+                                    lds_key_min(&key[key_slot<TS>(x - X0, y - Y0)], k);
                             }
                             p += 4;
                             if (p >= pend) break;
@@ -1289,15 +1396,16 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     constexpr uint32_t kHashSlots = (raster_queue_bytes<TS>() / sizeof(uint2)) >= 2048 ? 2048u : 1024u;
     static_assert(kHashSlots * sizeof(uint2) <= raster_queue_bytes<TS>(), "the table takes the batch queue's place");
     uint2 *hash_tab = reinterpret_cast<uint2 *>(qraw);
-    const bool hashed = L.pos_of && L.offs && end - beg <= kHashSlots / 2 && !(dbg & (1 << 21));
+    const bool hashed = L.pos_of && L.pairs && end - beg <= kHashSlots / 2 && !(dbg & (1 << 21));
     auto hash_of = [](uint32_t orig) { return (orig * 2654435761u) >> (kHashSlots == 2048u ? 21 : 22); };
     if (hashed) {
         for (uint32_t i = (uint32_t)tid; i < kHashSlots; i += kThreads) hash_tab[i] = make_uint2(0u, 0u);
         __syncthreads();
         for (uint32_t idx = beg + (uint32_t)tid; idx < end; idx += kThreads) {
-            const uint32_t at = L.entries[idx];
+            const uint2 e = reinterpret_cast<const uint2 *>(L.entries)[idx];
+            const uint32_t at = e.x;
             if (at >= L.T) continue;
-            const uint32_t tag = L.orig_of[at] + 1u;                     // (0 = empty slot)
+            const uint32_t tag = e.y + 1u;                               // (0 = empty slot)
             for (uint32_t h = hash_of(tag - 1u);; h = (h + 1u) & (kHashSlots - 1u)) {
                 const uint32_t was = atomicCAS(&hash_tab[h].x, 0u, tag);
                 if (was == 0u || was == tag) { hash_tab[h].y = at; break; }
@@ -1323,9 +1431,8 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
         const int dy = rw == TS ? p0 / TS : p0 / (TS / 2), dx = p0 - dy * rw;
         const int x = X0 + dx, y = Y0 + dy;
         if (x >= X1 || y >= Y1) continue;
-        const int p = dy * TS + dx;
         const I pix = (I)((I)y * (I)G.W + (I)x);
-        const uint32_t low = (uint32_t)key[p];
+        const uint32_t low = (uint32_t)key[key_slot<TS>(dx, dy)];
         if (low == KEY_LOW_PRIOR) {
             if (CLEAR) {
                 *elem(zb, pix) = 1e6f;
@@ -1354,7 +1461,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             np_[0] = 1.0f; np_[1] = 1.0f; np_[2] = 1.0f;
             continue;
         }
-        shade_and_store(proj, col, nrm, position_of(id), x, y, pix, zb, cb, nb, L.light);
+        shade_and_store(proj, col, nrm, position_of(id), x, y, pix, zb, cb, nb, L.light, (dbg >> 28) & 3);
         if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = (int32_t)id;
     }
     };
@@ -1524,6 +1631,7 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     tl.count = plan->count(par);
     tl.count_next = plan->count(par ^ 1);
     tl.entries = plan->entries();
+    tl.pairs = !direct && plan->last_frame_pairs;
     tl.bins = plan->direct();
     tl.capacity = direct ? (uint32_t)L.direct_cap : (uint32_t)L.capacity;
     tl.T = (uint32_t)plan->last_T;

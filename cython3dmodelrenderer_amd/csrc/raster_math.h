@@ -298,6 +298,13 @@ CR_DEV void load9(const float *__restrict__ p, float v[9])
     for (int i = 0; i < 9; ++i) v[i] = p[i];
 }
 
+// (experiment, development builds: the same through non-temporal loads — the lines are used once)
+CR_DEV void load9_nt(const float *__restrict__ p, float v[9])
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = __builtin_nontemporal_load(p + i);
+}
+
 CR_DEV TriXYZ load_tri(const float *__restrict__ p)
 {
     float v[9];
@@ -347,8 +354,25 @@ CR_DEV const float *elem(const float *base, I idx)
 template <typename I>
 CR_DEV void store_fragment(float z, const float c[9], const float n[9], float b1, float b2, float b3,
                            const Light &L, I pix, float *__restrict__ zb, float *__restrict__ cb,
-                           float *__restrict__ nb)
+                           float *__restrict__ nb, bool nt = false)
 {
+    if (nt) {       // (experiment, development builds: non-temporal stores)
+        float c0 = interp(c[0], c[3], c[6], b1, b2, b3);
+        float c1 = interp(c[1], c[4], c[7], b1, b2, b3);
+        float c2 = interp(c[2], c[5], c[8], b1, b2, b3);
+        const float n0 = interp(n[0], n[3], n[6], b1, b2, b3);
+        const float n1 = interp(n[1], n[4], n[7], b1, b2, b3);
+        const float n2 = interp(n[2], n[5], n[8], b1, b2, b3);
+        if (L.on) {
+            const float f = guro_factor(L, n0, n1, n2);
+            c0 *= f; c1 *= f; c2 *= f;
+        }
+        float *cp = elem(cb, (I)(pix * 3)), *np_ = elem(nb, (I)(pix * 3));
+        __builtin_nontemporal_store(z, elem(zb, pix));
+        __builtin_nontemporal_store(c0, cp); __builtin_nontemporal_store(c1, cp + 1); __builtin_nontemporal_store(c2, cp + 2);
+        __builtin_nontemporal_store(n0, np_); __builtin_nontemporal_store(n1, np_ + 1); __builtin_nontemporal_store(n2, np_ + 2);
+        return;
+    }
     *elem(zb, pix) = z;
     float c0 = interp(c[0], c[3], c[6], b1, b2, b3);
     float c1 = interp(c[1], c[4], c[7], b1, b2, b3);
@@ -372,15 +396,20 @@ template <typename I>
 CR_DEV void shade_and_store(const float *__restrict__ proj, const float *__restrict__ col,
                             const float *__restrict__ nrm, uint32_t tri, int X, int Y,
                             I pix, float *__restrict__ zb, float *__restrict__ cb,
-                            float *__restrict__ nb, const Light &L = Light{0.f, 0.f, 0.f, 0})
+                            float *__restrict__ nb, const Light &L = Light{0.f, 0.f, 0.f, 0}, int nt = 0)
 {
     const TriXYZ t = load_tri(elem(proj, (I)((I)tri * 9)));
     float c[9], n[9];
-    load9(elem(col, (I)((I)tri * 9)), c);
-    load9(elem(nrm, (I)((I)tri * 9)), n);
+    if (nt & 1) {
+        load9_nt(elem(col, (I)((I)tri * 9)), c);
+        load9_nt(elem(nrm, (I)((I)tri * 9)), n);
+    } else {
+        load9(elem(col, (I)((I)tri * 9)), c);
+        load9(elem(nrm, (I)((I)tri * 9)), n);
+    }
     float b1, b2, b3;
     barycentric(t, X, Y, b1, b2, b3);
-    store_fragment(interp(t.z0, t.z1, t.z2, b1, b2, b3), c, n, b1, b2, b3, L, pix, zb, cb, nb);
+    store_fragment(interp(t.z0, t.z1, t.z2, b1, b2, b3), c, n, b1, b2, b3, L, pix, zb, cb, nb, (nt & 2) != 0);
 }
 
 }  // namespace crender

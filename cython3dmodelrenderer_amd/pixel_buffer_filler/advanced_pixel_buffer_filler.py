@@ -750,24 +750,30 @@ class AdvancedPixelBufferFiller:
 
         What "resident" means: device tensors handed in by the caller are read in place, every frame,
         as they are then.  A model of 2^18 triangles or more (or ``presort=True``) is rendered from a
-        tile-coherent snapshot instead: for a model that counts its rewrites (``DeviceModel.generation``
+        tile-coherent snapshot instead.  For a model that counts its rewrites (``DeviceModel.generation``
         — part of that class's contract: every method that rewrites the by-triangle arrays bumps it, and
-        so must anybody who writes them through ``data_ptr()``) the snapshot is retaken here when the
-        count has moved; bare tensors under ``presort=True`` keep the snapshot of the last
-        ``render_model`` / ``render_arrays`` call."""
+        so must anybody who writes them through ``data_ptr()``: ``touch()``) a moved count is noticed
+        here: the snapshot is retaken, the swap chain drops what it binned ahead.  Bare tensors under
+        ``presort=True`` keep the snapshot of the last ``render_model`` / ``render_arrays`` call, and
+        bare tensors rewritten in place under a swap chain need ``render_model`` again (the protocol of
+        ``crender_pipeline_join``)."""
         model = self._model_ref() if self._model_ref is not None else None
-        if model is not None and self._order is not None and model.generation != self._model_generation:
-            # The resident copy is a tile-coherent SNAPSHOT of a model that has rewritten its arrays
-            # since (DeviceModel.shift / rotate / scale count their rewrites in `generation`): take a new
-            # one.  (Without a snapshot — small models, presort=False — the kernels read the model's
-            # own arrays and see every change anyway.)
+        if model is not None and model.generation != self._model_generation:
+            # The resident model has rewritten its arrays since (DeviceModel.shift / rotate / scale count
+            # their rewrites in `generation`).  Frames of the swap chain wait for the caller's stream
+            # again (the rewrite was enqueued there) and what was binned ahead from the old contents is
+            # dropped; a tile-coherent SNAPSHOT of the arrays is taken anew.  (The caller still must not
+            # rewrite arrays that frames in flight are reading: join() first.)
             self._join_pipe()
-            src = (model._vertices_by_triangles, model._colors_by_triangles, model._normals_by_triangles)
-            inputs = self._upload(src, ("model._vertices_by_triangles", "model._colors_by_triangles",
-                                        "model._normals_by_triangles"), composite=False)
-            self._inputs, self._order = self._tile_coherent(inputs, False, model.generation)
-            self._inputs_private = self._order is not None
-            self._inputs_stage = None
+            if self._order is not None:
+                src = (model._vertices_by_triangles, model._colors_by_triangles, model._normals_by_triangles)
+                inputs = self._upload(src, ("model._vertices_by_triangles", "model._colors_by_triangles",
+                                            "model._normals_by_triangles"), composite=False)
+                self._inputs, self._order = self._tile_coherent(inputs, False, model.generation)
+                self._inputs_private = self._order is not None
+                self._inputs_stage = None
+            elif self._pipe is not None:
+                self._pipe._args = None          # every slot is bound again: a binding voids its look-ahead
             self._model_generation = model.generation
         use_pipe = self._pipeline if pipelined is None else (pipelined and self._pipeline)
         if not use_pipe:

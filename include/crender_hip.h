@@ -154,6 +154,8 @@ CRENDER_API int crender_plan_poll_bin_usage(crender_plan *plan, uint64_t ticket,
  * The caller may hand the kernels a PERMUTATION of its triangle arrays (all three alike), sorted
  * so that triangles of one screen region are neighbours in memory — crender_tile_order_keys
  * writes a sort key per triangle (Morton code of the 32-pixel tile of its projected centroid) —
+ * (the key is in fact the Morton code of the 4-pixel CELL, whose prefixes are the codes of the 8- to
+ * 64-pixel tiles: neighbours in the frame stay neighbours in memory within a tile too) —
  * and tell the plan about it: d_orig_of[position] = index in the caller's own arrays,
  * d_pos_of[index] = position (uint32 [T] each, device memory that outlives the plan's frames;
  * NULL, NULL = no permutation).  Results are unchanged: depth ties still go to the highest index
