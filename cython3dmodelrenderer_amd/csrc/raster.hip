@@ -213,7 +213,11 @@ CR_DEV uint32_t pack_box(uint32_t xy, uint32_t wh, int X0, int Y0)
     return (uint32_t)((int)(xy & 0xFFFF) - X0) | ((uint32_t)((int)(xy >> 16) - Y0) << 6) | ((wh & 0x7Fu) << 12) |
            ((wh >> 16) << 19);
 }
-CR_DEV uint32_t packed_wh(uint32_t b) { return ((b >> 12) & 0x7Fu) | ((b >> 19) << 16); }
+CR_DEV uint32_t packed_wh(uint32_t b) { return ((b >> 12) & 0x7Fu) | (((b >> 19) & 0x7Fu) << 16); }
+// bits 26..31 of the word: how many records WITHOUT work follow this one in its wavefront's 64 slots (the
+// run-wise sweep steps over them; a frame rendered alone clips every list to a quadrant of its tile, and
+// three records in four have no work there)
+CR_DEV uint32_t packed_skip(uint32_t b) { return b >> 26; }
 CR_DEV uint32_t packed_xy(uint32_t b, int X0, int Y0)
 {
     return (uint32_t)(X0 + (int)(b & 0x3Fu)) | ((uint32_t)(Y0 + (int)((b >> 6) & 0x3Fu)) << 16);
@@ -790,16 +794,24 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             }
         } else {
             tile = (dbg & 8) ? xcd_band_tile(m, G.ntiles) : m;
-            const bool super_map = (dbg & (1 << 27)) && (G.ntx & 7) == 0 && (G.nty & 7) == 0 && (G.ntiles & 511) == 0;
+            // Tile-coherent triangle order (lists of (position, index) pairs: millions of small triangles):
+            // neighbouring tiles read the same records along their common border — a sixth of a list —
+            // and workgroup m runs on XCD m % 8, each XCD with an L2 of its own: dealt round-robin, the
+            // neighbours sit on eight different XCDs and every shared line is fetched once per XCD that
+            // wants it.  Instead blocks of 16 x 16 tiles are dealt round-robin to the XCDs and each
+            // block's tiles are walked one after another on its XCD (192 tiles in flight there: all
+            // neighbours): 10 M small triangles 1 949 -> 1 642 MB fetched per launch, the launch itself
+            // +1 % (blocks of 2 / 4 / 8 tiles: 1 738 / 1 700 / 1 667 MB, +3.5 / +2 / +2.5 %;
+            // profiles/r05/ab_block_map_synth10m.txt).  Needs whole blocks, eight at a time.
+            constexpr uint32_t SL = 4, SB = 1u << SL;
+            const bool super_map = (L.pairs != 0) != ((dbg & (1 << 27)) != 0) && (G.ntx & (SB - 1)) == 0 &&
+                                   (G.nty & (SB - 1)) == 0 && (((uint32_t)G.ntiles >> (2 * SL)) & 7u) == 0;
             if (super_map) {
-                // (experiment) workgroup m runs on XCD m % 8: deal 8 x 8-tile blocks round-robin to the
-                // XCDs and walk each block's tiles one after another on its XCD, so that neighbouring
-                // tiles — which share the records along their common border — meet in one L2
                 const uint32_t xcd = (uint32_t)m & 7u, j = (uint32_t)m >> 3;
-                const uint32_t sidx = (j >> 6) * 8u + xcd, local = j & 63u;
-                const uint32_t SX = (uint32_t)G.ntx >> 3;
+                const uint32_t sidx = (j >> (2 * SL)) * 8u + xcd, local = j & (SB * SB - 1u);
+                const uint32_t SX = (uint32_t)G.ntx >> SL;
                 const uint32_t sy = sidx / SX, sx = sidx - sy * SX;
-                tile = (int)((sy * 8u + (local >> 3)) * (uint32_t)G.ntx + sx * 8u + (local & 7u));
+                tile = (int)((sy * SB + (local >> SL)) * (uint32_t)G.ntx + sx * SB + (local & (SB - 1u)));
             }
             // Large grids: scatter the dispatch order (block b -> tile b * stride mod ntiles) so
             // that a band of covered tiles is spread over the whole launch instead of arriving
@@ -1006,7 +1018,12 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             q.x1[tid] = cur_t.x1; q.y1[tid] = cur_t.y1; q.z1[tid] = cur_t.z1;
             q.x2[tid] = cur_t.x2; q.y2[tid] = cur_t.y2; q.z2[tid] = cur_t.z2;
             q.tri[tid] = cur_id;
-            q.box[tid] = pack_box(box_xy, box_wh, X0, Y0);
+            {
+                const unsigned long long live = __builtin_amdgcn_ballot_w64(box_wh != 0);
+                const unsigned long long after = lane == 63 ? 0ull : live >> (lane + 1);
+                const uint32_t skip = after ? (uint32_t)__builtin_ctzll(after) : (uint32_t)(63 - lane);
+                q.box[tid] = pack_box(box_xy, box_wh, X0, Y0) | (skip << 26);
+            }
             if constexpr (!either) q.big.blk_scan[tid] = incl - my_blocks;     // (32-pixel tiles: once the sweep is chosen)
             if (lane == 63) q.wave_blocks[wave] = incl;
             if constexpr (either) {
@@ -1149,7 +1166,8 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                 // ONE flat loop, its state stepped with selects: with `if (row done) { if (record done) ... }`
                 // the compiler turned the walk into three nested loops (pairs of a row, rows of a record,
                 // records) in which every lane waits for the wavefront's longest row and tallest box —
-                // twice the time.  A record without work (clipped away: rare) costs an idle trip.
+                // twice the time.  Records without work are stepped over (packed_skip); the first slot of
+                // a wavefront's 64 may still be one: an idle trip.
                 while (left > 0) {
                     const uint32_t pb = q.box[r];
                     const uint32_t xy = packed_xy(pb, X0, Y0), wh = packed_wh(pb);
@@ -1184,7 +1202,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                     dy += row_done ? 1 : 0;
                     const bool rec_done = dy >= bh;
                     dy = rec_done ? 0 : dy;
-                    r += rec_done ? 1 : 0;
+                    r += rec_done ? 1 + (int)packed_skip(pb) : 0;
                 }
             };
             if constexpr (TS == 32) {
