@@ -701,6 +701,58 @@ CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const flo
     }
 }
 
+// ---- a tile's workgroup ---------------------------------------------------------------------------
+// What every path of a tile's workgroup works with: the frame's arrays, this workgroup's rectangle
+// (a whole tile, or one half / quadrant of a heavy one), its list, its LDS.  The paths below are
+// functions of their own — which tile (pick_tile), the two small-record sweeps (sweep_items, sweep_runs32),
+// the pixel path of 16-pixel tiles, the pixel owners (owner_path32 -> owner_tile), the culled block sweep,
+// the two walks of 64-pixel tiles, the resolve — all inlined into raster_body, which queues the batches.
+template <int TS>
+struct Tile {
+    const float *proj, *col, *nrm;
+    const TileLists &L;
+    float *zb, *cb, *nb;
+    int32_t *win;
+    const Geom &G;
+    unsigned long long *key;     // LDS: the key plane (the pixel owners' per-record words instead)
+    unsigned char *qraw;         // LDS: the batch queue (Rec16 records on 16-pixel tiles, else a WorkQueue)
+    int dbg;                     // CRENDER_DEBUG of a development build, 0 in the product
+    int X0, Y0, X1, Y1;          // the rectangle
+    int rw, quad;                // its width in the key plane's terms; -1 = whole tile, 0..3 = part of a heavy one
+    uint32_t beg, end;           // the tile's list
+#ifdef CRENDER_STAMPS
+    size_t stamp_base;
+#endif
+};
+#ifdef CRENDER_DEV_KNOBS
+#define CR_TILE_DBG(c) [[maybe_unused]] const int dbg = (c).dbg
+#else
+#define CR_TILE_DBG(c) [[maybe_unused]] constexpr int dbg = 0
+#endif
+#ifdef CRENDER_STAMPS
+#define CR_TILE_STAMPS(c) [[maybe_unused]] const size_t stamp_base = (c).stamp_base
+#else
+#define CR_TILE_STAMPS(c) do { } while (0)
+#endif
+// (the names the bodies below were written with)
+#define CR_TILE_LOCALS(c)                                                                                        \
+    [[maybe_unused]] const float *const proj = (c).proj, *const col = (c).col, *const nrm = (c).nrm;             \
+    [[maybe_unused]] const TileLists &L = (c).L;                                                                 \
+    [[maybe_unused]] float *const zb = (c).zb, *const cb = (c).cb, *const nb = (c).nb;                           \
+    [[maybe_unused]] int32_t *const win = (c).win;                                                               \
+    [[maybe_unused]] const Geom &G = (c).G;                                                                      \
+    [[maybe_unused]] unsigned long long *const key = (c).key;                                                    \
+    [[maybe_unused]] unsigned char *const qraw = (c).qraw;                                                       \
+    [[maybe_unused]] WorkQueue &q = *reinterpret_cast<WorkQueue *>((c).qraw);                  /* TS != 16 */    \
+    [[maybe_unused]] Rec16 *const recs = reinterpret_cast<Rec16 *>((c).qraw);                  /* TS == 16 */    \
+    [[maybe_unused]] uint32_t *const scan16 = reinterpret_cast<uint32_t *>((c).qraw + sizeof(Rec16) * kBatch16); \
+    [[maybe_unused]] uint32_t *const wave16 = scan16 + kThreads;                                                 \
+    [[maybe_unused]] const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                              \
+    [[maybe_unused]] const int X0 = (c).X0, Y0 = (c).Y0, X1 = (c).X1, Y1 = (c).Y1, rw = (c).rw, quad = (c).quad; \
+    [[maybe_unused]] const uint32_t beg = (c).beg, end = (c).end;                                                \
+    CR_TILE_DBG(c);                                                                                              \
+    CR_TILE_STAMPS(c)
+
 // the batch: records array-of-structures on 16-pixel tiles (Rec16), else the WorkQueue
 template <int TS>
 constexpr size_t raster_queue_bytes()
@@ -708,49 +760,33 @@ constexpr size_t raster_queue_bytes()
     return TS == 16 ? sizeof(Rec16) * kBatch16 + sizeof(uint32_t) * (kThreads + 8) : sizeof(WorkQueue);
 }
 
-// Workgroup `b` of a raster launch (the kernels below hand in their LDS: k_frame runs binning
-// wavefronts of another frame in the same launch).
+// Which tile workgroup `b` of a raster launch takes, and which part of it; false: the workgroup is done
+// (it built the dispatch order, found its helper slot empty, or cleared its group of empty tiles).
 template <int TS, bool CLEAR>
-CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict__ col,
-                        const float *__restrict__ nrm, const TileLists &L,
-                        float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
-                        int32_t *__restrict__ win, const Geom &G, int dbg_arg, int b,
-                        unsigned long long *key, unsigned char *qraw)
+CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad, bool &helper_out)
 {
-#ifdef CRENDER_STAMPS
-    // frames of a swap chain stamp into a region of their slot (bits 24..26 of dbg_arg), 8192 workgroups each
-    const size_t stamp_base = ((size_t)((dbg_arg >> 24) & 7) * 8192 + blockIdx.x) * 16;
-#endif
-    WorkQueue &q = *reinterpret_cast<WorkQueue *>(qraw);                 // (TS != 16 only)
-    Rec16 *recs = reinterpret_cast<Rec16 *>(qraw);                       // (TS == 16 only)
-    uint32_t *scan16 = reinterpret_cast<uint32_t *>(qraw + sizeof(Rec16) * kBatch16);
-    uint32_t *wave16 = scan16 + kThreads;
-    constexpr int kBatch = TS == 16 ? kBatch16 : kThreads;
-#ifdef CRENDER_DEV_KNOBS
-    const int dbg = dbg_arg;
-#else
-    constexpr int dbg = 0;
-    (void)dbg_arg;
-#endif
+    const TileLists &L = c.L;
+    const Geom &G = c.G;
+    float *const zb = c.zb, *const cb = c.cb, *const nb = c.nb;
+    int32_t *const win = c.win;
+    unsigned char *const qraw = c.qraw;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-
+    CR_TILE_DBG(c);
     // ---- which tile, and which part of it --------------------------------------------------
     // grid = [order builder, if ordered][3 * hmax helpers][ntiles main workgroups, one tile each]
     if (L.order_next) {
         if (b == 0) {
             build_order(L.count, G.ntx, G.nty, L.order_next, L.grouped_next, L.hint_next, reinterpret_cast<uint32_t *>(qraw), group_tiles(TS));
-            return;
+            return false;
         }
         b -= 1;
     }
     const bool helper = b < L.nhelp;
-    int quad = -1;               // -1 = the whole tile, 0..3 = one part of a heavy tile (half or quadrant)
-    int tile;
+    quad = -1;                   // -1 = the whole tile, 0..3 = one part of a heavy tile (half or quadrant)
     if (helper) {
         // part 1..3 of the heavy tile registered in this workgroup's slot, if any
         const uint32_t v = L.heavy_slots[b];
-        if (v == 0) return;                        // (same word for every thread: uniform)
+        if (v == 0) return false;                        // (same word for every thread: uniform)
         tile = (int)v - 1;
         quad = 1 + b % 3;
     } else {
@@ -771,7 +807,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                 // the order's last section: up to kGroup empty tiles per workgroup, cleared with two
                 // float4 stores per thread and tile (no list to look at: the binning pass vouches
                 // for their emptiness, see first_entry_of)
-                if (m >= ns + ng) return;
+                if (m >= ns + ng) return false;
                 constexpr int kG = group_tiles(TS);
                 const int first = ns + (m - ns) * kG;
                 const int ntl = G.ntiles - first < kG ? G.ntiles - first : kG;
@@ -790,7 +826,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                         clear_rect<TS>(zb, cb, nb, win, G.W, x0, y0, (x0 + TS < G.W) ? x0 + TS : G.W,
                                        (y0 + TS < G.y1) ? y0 + TS : G.y1, L.vec_clear != 0, tid);
                 }
-                return;
+                return false;
             }
         } else {
             tile = (dbg & 8) ? xcd_band_tile(m, G.ntiles) : m;
@@ -842,565 +878,402 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             }
         }
     }
-    const int ty = G.ntx_magic ? (int)__umulhi((uint32_t)tile, G.ntx_magic) : tile / G.ntx;
-    const int tx = tile - ty * G.ntx;
-    int X0 = tx * TS, Y0 = G.y0 + ty * TS;
-    int X1 = (X0 + TS < G.W) ? (X0 + TS) : G.W;
-    int Y1 = (Y0 + TS < G.y1) ? (Y0 + TS) : G.y1;
+    b_out = b;
+    helper_out = helper;
+    return true;
+}
 
-    CR_STAMP(0);
-#ifdef CRENDER_STAMPS
-    if (g_stamps && threadIdx.x == 0) {
-        g_stamps[stamp_base + 7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID
-        g_stamps[stamp_base + 8] = (unsigned long long)tile;
-        g_stamps[stamp_base + 10] = __builtin_amdgcn_s_memtime();
-    }
-#endif
-    // the tile's triangle list: a run of the scanned index array, or (direct bins, offs == null)
-    // a fixed-capacity slab of entries whose fill count k_setup_wave left in count[tile]
-    uint32_t beg, end;
-    if (L.offs) {
-        beg = L.offs[tile];
-        end = L.offs[tile + 1];
-        if (end > L.capacity) end = L.capacity;
-        if (beg > end) beg = end;
-    } else {
-        const uint32_t n = L.count[tile];
-        beg = (uint32_t)tile * L.capacity;
-        end = beg + (n < L.capacity ? n : L.capacity);
-    }
-    if (!helper) {
-        if (L.heavy_flag && L.heavy_flag[tile]) quad = 0;
-        // the other parity's counter of this tile: zero for the next frame
-        if (tid == 0) L.count_next[tile] = 0;
-    }
-    int rw = TS;                 // width of this workgroup's rectangle in the key plane's terms
-    if (quad >= 0) {
-        constexpr int HS = TS / 2;
-        if (end - beg >= quad_at(TS)) {         // four quadrants
-            X0 += (quad & 1) * HS; Y0 += (quad >> 1) * HS;
-            if (X1 > X0 + HS) X1 = X0 + HS;
-            rw = HS;
-        } else {                                // two halves; parts 2 and 3 have nothing to do
-            if (quad >= 2) {
-                if (tid == 0) L.heavy_slots[b] = 0;
-                return;
-            }
-            Y0 += quad * HS;
+// depth keys of the rectangle: the prior buffer value (or the cleared value) per pixel
+template <int TS, bool CLEAR>
+CR_DEV void init_keys(const Tile<TS> &c)
+{
+    CR_TILE_LOCALS(c);
+    const unsigned long long key_clear = make_key(zord(1e6f), KEY_LOW_PRIOR);
+    for (int p = tid; p < TS * TS; p += kThreads) {
+        unsigned long long k = key_clear;
+        if (!CLEAR) {
+            const int x = X0 + (p % TS), y = Y0 + (p / TS);
+            if (x < X1 && y < Y1) k = make_key(zord_prior(zb[(size_t)y * G.W + x]), KEY_LOW_PRIOR);
         }
-        if (Y1 > Y0 + HS) Y1 = Y0 + HS;
-        if (X1 < X0) X1 = X0;
-        if (Y1 < Y0) Y1 = Y0;
+        key[key_slot<TS>(p % TS, p / TS)] = k;
     }
-    if (dbg & 1) end = beg;   // ablation: no coverage work (development build)
+}
 
-    const bool work = beg != end && X0 < X1 && Y0 < Y1;     // (uniform over the workgroup)
-    if (!work) {
-        // nothing to rasterize here: the rectangle keeps its content, or (fused clear) becomes
-        // background — no key plane, no barriers
-        if (CLEAR && X0 < X1 && Y0 < Y1) clear_rect<TS>(zb, cb, nb, win, G.W, X0, Y0, X1, Y1, L.vec_clear && quad < 0, tid);
-        CR_STAMP(3);
-    } else {
-    // 16-pixel tiles with direct bins (at most 65536 triangles): a depth key's low word carries
-    // the triangle index in its high half as usual and, in its low half, where the record sits
-    // in LDS — batch and slot — so that the resolve takes the winner's edge constants from there
-    const bool slotted = TS == 16 && !L.offs;
-    // first batch of the tile's list straight into registers
-    uint32_t cur_id = 0, cur_bx = 0, cur_by = 0;
-    TriXYZ cur_t{};
-    bool cur_ok = tid < kBatch && beg + tid < end;
-    if (cur_ok) cur_ok = load_record(L, proj, G, beg + tid, cur_id, cur_t, cur_bx, cur_by);
-
-    // depth keys of the tile: the prior buffer value (or the cleared value) per pixel
-    // (32-pixel tiles: once it is known that the tile is not the pixel owners', see below)
-    auto init_keys = [&]() {
-        const unsigned long long key_clear = make_key(zord(1e6f), KEY_LOW_PRIOR);
-        for (int p = tid; p < TS * TS; p += kThreads) {
-            unsigned long long k = key_clear;
-            if (!CLEAR) {
-                const int x = X0 + (p % TS), y = Y0 + (p / TS);
-                if (x < X1 && y < Y1) k = make_key(zord_prior(zb[(size_t)y * G.W + x]), KEY_LOW_PRIOR);
-            }
-            key[key_slot<TS>(p % TS, p / TS)] = k;
-        }
-    };
-    if constexpr (TS != 32) init_keys();
-    CR_STAMP(1);
+// Short batch on a 16-pixel tile: one PIXEL per thread, every thread walks the
+// records (LDS broadcast reads), the running minimum stays in a register — no
+// block scan, no record search, no LDS atomics.  A wavefront (4 rows of the tile)
+// skips a record whose box misses its rows.
+CR_DEV void pixel_path16(const Tile<16> &c, uint32_t left, bool first, const TriXYZ &cur_t, uint32_t key_low,
+                         uint32_t box_xy, uint32_t box_wh)
+{
+    [[maybe_unused]] constexpr int TS = 16;
+    CR_TILE_LOCALS(c);
+    if (!first) __syncthreads();
+    if (tid < (int)left) put_rec16(&recs[tid], cur_t, key_low, box_xy, box_wh);
+    __syncthreads();
 #ifdef CRENDER_STAMPS
-    if (g_stamps && tid == 0) {
-        g_stamps[stamp_base + 4] = end - beg;
-        g_stamps[stamp_base + 9] = (unsigned long long)(quad + 1);
+    if (first) CR_STAMP(6);
+#endif
+    const int px = X0 + (tid & 15), py = Y0 + (tid >> 4);
+    unsigned long long best = key[tid];
+    for (uint32_t r = 0; r < left; ++r) {
+        const uint32_t wh = recs[r].box_wh & ~kRecFast;
+        if (wh == 0) continue;
+        const uint32_t xy = recs[r].box_xy;
+        const int bx0 = (int)(xy & 0xFFFF), by0 = (int)(xy >> 16);
+        const bool in = px >= bx0 && px < bx0 + (int)(wh & 0xFFFF) &&
+                        py >= by0 && py < by0 + (int)(wh >> 16);
+        if (!wave_any(in)) continue;
+        const Rec16Regs R = load_rec16(&recs[r]);
+        unsigned long long k;
+        if (in && fragment16(R, px, py, k) && k < best) best = k;
     }
-#endif
+    key[tid] = best;
+}
 
-    for (uint32_t base = beg; base < end; base += kBatch) {
-        // ---- queue this batch: one record per thread, slot = thread index --------------
-        uint32_t box_xy = 0, box_wh = 0;
-        if (cur_ok) {
-            int xl = (int)(cur_bx & 0xFFFF), xr = (int)(cur_bx >> 16);
-            int yt = (int)(cur_by & 0xFFFF), yb = (int)(cur_by >> 16);
-            if (xl < X0) xl = X0;
-            if (xr > X1) xr = X1;
-            if (yt < Y0) yt = Y0;
-            if (yb > Y1) yb = Y1;
-            if (xl < xr && yt < yb) {
-                box_xy = (uint32_t)xl | ((uint32_t)yt << 16);
-                box_wh = (uint32_t)(xr - xl) | ((uint32_t)(yb - yt) << 16);
-                // A large triangle's pixel box covers about twice its area: a good part of the
-                // entries of a frame of large triangles (bunny 4096^2: 8 per tile) name tiles the
-                // triangle never touches.  Exact test on (box ∩ tile); not worth its ~80
-                // instructions for a small box.
-                if (TS >= 32 && (xr - xl) * (yb - yt) >= 256 &&
-                    rect_surely_missed(make_setup(cur_t, false), xl, xr - 1, yt, yb - 1))
-                    box_wh = 0;
+// Per-pixel sweep: every pixel of every clipped box is one work item; thread t takes
+// items t, t + 256, ...  All lanes work on a sample that lies in its box (a 4x4 block
+// of a small box is mostly empty: 71 % of T-Rex 1024^2's block lanes were inside their
+// box, 40-50 % on its busiest tiles, 35 % for the 10 M small triangles), and there is
+// no per-group record walk.  The item's record comes from a two-level search of the
+// prefix sums (most batches fit the first wavefront's 64 slots: then no wavefront
+// selection and only log2 of the record count steps).
+template <int TS>
+CR_DEV void sweep_items(const Tile<TS> &c, const uint32_t *scan, const uint32_t *wo_, int total_, int nrec)
+{
+    CR_TILE_LOCALS(c);
+    const int first_n = nrec <= 1 ? 1 : (nrec > 64 ? 64 : 1 << (32 - __clz(nrec - 1)));
+    for (int e = tid; e < total_; e += kThreads) {
+        uint32_t i;
+        int r;
+        if (nrec <= 64) {
+            int lo = 0;
+            for (int n = first_n; n > 1;) {     // last slot with scan <= e
+                const int half = n >> 1;
+                if (scan[lo + half] <= (uint32_t)e) lo += half;
+                n -= half;
             }
-        }
-        const uint32_t key_low = slotted ? ((0xFFFFu - (cur_id & 0xFFFFu)) << 16) | ((((base - beg) / kBatch) & 0xFFu) << 8) | (uint32_t)tid
-                                         : 0xFFFFFFFEu - cur_id;
-#ifdef CRENDER_STAMPS
-        if (base == beg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CR_STAMP(5); }
-#endif
-        if constexpr (TS == 16) {
-            // Short batch on a 16-pixel tile: one PIXEL per thread, every thread walks the
-            // records (LDS broadcast reads), the running minimum stays in a register — no
-            // block scan, no record search, no LDS atomics.  A wavefront (4 rows of the tile)
-            // skips a record whose box misses its rows.
-            const uint32_t left = end - base;
-            const uint32_t pix_max = (dbg >> 16) & 0xFF ? (uint32_t)((dbg >> 16) & 0xFF) - 1u : kPixelPathRecords;
-            if (left <= pix_max) {
-                if (base != beg) __syncthreads();
-                if (tid < (int)left) put_rec16(&recs[tid], cur_t, key_low, box_xy, box_wh);
-                __syncthreads();
-#ifdef CRENDER_STAMPS
-                if (base == beg) CR_STAMP(6);
-#endif
-                const int px = X0 + (tid & 15), py = Y0 + (tid >> 4);
-                unsigned long long best = key[tid];
-                for (uint32_t r = 0; r < left; ++r) {
-                    const uint32_t wh = recs[r].box_wh & ~kRecFast;
-                    if (wh == 0) continue;
-                    const uint32_t xy = recs[r].box_xy;
-                    const int bx0 = (int)(xy & 0xFFFF), by0 = (int)(xy >> 16);
-                    const bool in = px >= bx0 && px < bx0 + (int)(wh & 0xFFFF) &&
-                                    py >= by0 && py < by0 + (int)(wh >> 16);
-                    if (!wave_any(in)) continue;
-                    const Rec16Regs R = load_rec16(&recs[r]);
-                    unsigned long long k;
-                    if (in && fragment16(R, px, py, k) && k < best) best = k;
-                }
-                key[tid] = best;
-                cur_ok = false;
-                continue;   // (this was the list's last batch)
-            }
-        }
-        // 16-pixel tiles: the work is flattened per PIXEL of the clipped boxes, not per block
-        // (see the sweep below); elsewhere per 16-pixel block
-        constexpr bool per_pixel = TS == 16;   // always the per-pixel sweep
-        constexpr bool either = TS == 32;      // counted both ways, the batch picks its sweep
-        // wave-inclusive scan of the work counts
-        // (per-pixel work is counted in ITEMS of kItemPixels / kItemPixels32 x-neighbours of a box row)
-        const uint32_t my_px = (uint32_t)(((box_w(box_wh) + kItemPixels32 - 1) / kItemPixels32) * box_h(box_wh));
-        // (16-pixel tiles: an item is a PAIR of x-neighbours of a box row, see the sweep)
-        const uint32_t my_blocks = per_pixel ? (uint32_t)(((box_w(box_wh) + kItemPixels - 1) / kItemPixels) * box_h(box_wh))
-                                             : (uint32_t)blocks_of(box_wh);
-        const uint32_t incl = wave_incl_sum(my_blocks);
-        uint32_t incl_px = my_px;
-        if constexpr (either) incl_px = wave_incl_sum(my_px);
-        // previous batch's sweeps must be over before the queue is overwritten (the first batch has
-        // none before it: the barrier behind the queue orders the key initialisation too)
-        if (base != beg) __syncthreads();
-        if constexpr (TS == 16) {
-            if (tid < kBatch) put_rec16(&recs[tid], cur_t, key_low, box_xy, box_wh);
-            scan16[tid] = incl - my_blocks;
-            if (lane == 63) wave16[wave] = incl;
+            r = lo;
+            i = (uint32_t)e - scan[lo];
         } else {
-            q.x0[tid] = cur_t.x0; q.y0[tid] = cur_t.y0; q.z0[tid] = cur_t.z0;
-            q.x1[tid] = cur_t.x1; q.y1[tid] = cur_t.y1; q.z1[tid] = cur_t.z1;
-            q.x2[tid] = cur_t.x2; q.y2[tid] = cur_t.y2; q.z2[tid] = cur_t.z2;
-            q.tri[tid] = cur_id;
+            r = find_record(scan, wo_, e, i);
+        }
+        if constexpr (TS == 16) {
+            const Rec16Regs R = load_rec16(&recs[r]);
+            const uint32_t xy = __float_as_uint(R.c.z);
+            const int bw = box_w(__float_as_uint(R.c.w));
+            // kItemPixels samples per item — x-neighbours of one box row — share the
+            // item's record search, its six LDS reads and its decode (a third of a
+            // sample's instructions and most of an iteration's dependent LDS round
+            // trips); a box width that is no multiple wastes part of an item per row.
+            const int bwn = (bw + kItemPixels - 1) / kItemPixels;
+            const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
+            const int px0 = ((int)i - dy * bwn) * kItemPixels;
+            const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
+            unsigned long long *kp = &key[key_slot<TS>(x - X0, y - Y0)];
+#pragma unroll
+            for (int j = 0; j < kItemPixels; ++j) {
+                unsigned long long k;
+                if (fragment16(R, x + j, y, k) && (j == 0 || px0 + j < bw)) lds_key_min(kp + j, k);
+            }
+        } else {
+            const uint32_t xy = packed_xy(q.box[r], X0, Y0);
+            const int bw = box_w(packed_wh(q.box[r]));
+            const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
+                           q.x2[r], q.y2[r], q.z2[r]};
+            const uint32_t id = q.tri[r];
+            // the item's samples share its record search, its twelve LDS reads, the nine
+            // edge constants and the refined reciprocals (raster_math.h (2)): per sample
+            // that was 150 vector instructions, a pair costs 175
+            TriSetup st;
             {
-                const unsigned long long live = __builtin_amdgcn_ballot_w64(box_wh != 0);
-                const unsigned long long after = lane == 63 ? 0ull : live >> (lane + 1);
-                const uint32_t skip = after ? (uint32_t)__builtin_ctzll(after) : (uint32_t)(63 - lane);
-                q.box[tid] = pack_box(box_xy, box_wh, X0, Y0) | (skip << 26);
+                st.x0 = t.x0; st.y0 = t.y0; st.z0 = t.z0; st.x1 = t.x1; st.y1 = t.y1; st.z1 = t.z1;
+                st.x2 = t.x2; st.y2 = t.y2; st.z2 = t.z2;
+                st.l01 = t.x1 - t.x2; st.l02 = t.y1 - t.y2;
+                st.l11 = t.x2 - t.x0; st.l12 = t.y2 - t.y0;
+                st.l21 = t.x0 - t.x1; st.l22 = t.y0 - t.y1;
+                st.l03 = q.pre.l03[r]; st.l13 = q.pre.l13[r]; st.l23 = q.pre.l23[r];
+                st.r1 = q.pre.r1[r]; st.r2 = q.pre.r2[r]; st.r3 = q.pre.r3[r];
+                st.fast = st.r1 != 0.0f;
+                st.rej1 = st.rej2 = st.rej3 = 0.0f;
             }
-            if constexpr (!either) q.big.blk_scan[tid] = incl - my_blocks;     // (32-pixel tiles: once the sweep is chosen)
-            if (lane == 63) q.wave_blocks[wave] = incl;
-            if constexpr (either) {
-                if (lane == 63) q.wave_px[wave] = incl_px;
+            const int bwn = (bw + kItemPixels32 - 1) / kItemPixels32;
+            // i / bwn for i < 1024, bwn <= 32: the approximate reciprocal is exact enough
+            const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
+            const int px0 = ((int)i - dy * bwn) * kItemPixels32;
+            const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
+#pragma unroll
+            for (int j = 0; j < kItemPixels32; ++j) {
+                float n1, n2, n3;
+                numerators(st, x + j, y, n1, n2, n3);
+                unsigned long long k;
+                if (fragment_from(st, id, n1, n2, n3, true, k) && (j == 0 || px0 + j < bw))
+                    lds_key_min(&key[key_slot<TS>(x + j - X0, y - Y0)], k);
             }
         }
-        __syncthreads();  // queue complete
-#ifdef CRENDER_STAMPS
-        if (base == beg) CR_STAMP(6);
-#endif
+    }
+}
 
-        // ---- sweep: the batch's work items, flattened and split evenly -------------------------
+// The same items — pairs of x-neighbours of the clipped boxes' rows — in RUNS: thread t takes
+// items [t c, (t + 1) c) of the batch (c = ceil(total / 256)), finds the record of its first
+// item by the search above ONCE and then walks: next pair of the row, next row, next record.
+// Per item that is no search (6 dependent LDS reads and ~55 of ~230 vector instructions on
+// batches of more than 64 records) and no division for the row; the record is re-read
+// from LDS per item as before (registers: the 32-pixel kernel has none to spare), one round
+// trip.  Lanes of a wavefront hold neighbouring records (consecutive LDS banks), every lane
+// makes the same number of trips.
+CR_DEV void sweep_runs32(const Tile<32> &c, const uint32_t *wo_, int total_)
+{
+    constexpr int TS = 32;
+    CR_TILE_LOCALS(c);
+    const int chunk = (total_ + kThreads - 1) / kThreads;
+    int e = tid * chunk;
+    int left = (e + chunk < total_ ? e + chunk : total_) - e;       // items of this thread's run
+    if (left <= 0) return;
+    uint32_t i;
+    int r = find_record(q.pre.px_scan, wo_, e, i);
+    int dy, px0;             // the item within its record: row of the box, first pixel of the pair
+    {
+        const int bwn = (box_w(packed_wh(q.box[r])) + kItemPixels32 - 1) / kItemPixels32;
+        dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
+        px0 = ((int)i - dy * bwn) * kItemPixels32;
+    }
+    // ONE flat loop, its state stepped with selects: with `if (row done) { if (record done) ... }`
+    // the compiler turned the walk into three nested loops (pairs of a row, rows of a record,
+    // records) in which every lane waits for the wavefront's longest row and tallest box —
+    // twice the time.  Records without work are stepped over (packed_skip); the first slot of
+    // a wavefront's 64 may still be one: an idle trip.
+    while (left > 0) {
+        const uint32_t pb = q.box[r];
+        const uint32_t xy = packed_xy(pb, X0, Y0), wh = packed_wh(pb);
+        const int bw = box_w(wh), bh = box_h(wh);
+        const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r], q.x2[r], q.y2[r], q.z2[r]};
+        const uint32_t id = q.tri[r];
+        TriSetup st;
         {
-            const int l = tid & 15, lx = l & 3, ly = l >> 2;
-            uint32_t wo[kThreads / 64 + 1];
-            wo[0] = 0;
+            st.x0 = t.x0; st.y0 = t.y0; st.z0 = t.z0; st.x1 = t.x1; st.y1 = t.y1; st.z1 = t.z1;
+            st.x2 = t.x2; st.y2 = t.y2; st.z2 = t.z2;
+            st.l01 = t.x1 - t.x2; st.l02 = t.y1 - t.y2;
+            st.l11 = t.x2 - t.x0; st.l12 = t.y2 - t.y0;
+            st.l21 = t.x0 - t.x1; st.l22 = t.y0 - t.y1;
+            st.l03 = q.pre.l03[r]; st.l13 = q.pre.l13[r]; st.l23 = q.pre.l23[r];
+            st.r1 = q.pre.r1[r]; st.r2 = q.pre.r2[r]; st.r3 = q.pre.r3[r];
+            st.fast = st.r1 != 0.0f;
+            st.rej1 = st.rej2 = st.rej3 = 0.0f;
+        }
+        const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
 #pragma unroll
-            for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + (TS == 16 ? wave16[w] : q.wave_blocks[w]);
-            const int total = (int)wo[kThreads / 64];
-            const int nrec = (int)((end - base) < (uint32_t)kBatch ? (end - base) : (uint32_t)kBatch);
-            const uint32_t blk_excl = incl - my_blocks;
-            bool small_by_pixel = false;    // 32-pixel tiles: small records go per pixel too
-            if constexpr (either) small_by_pixel = total < 16 * nrec && !(dbg & 8192);
-            if constexpr (either) {
-                if (small_by_pixel) {
-                    // every record's thread works out, ONCE, what an item of its record would otherwise
-                    // work out again (9 items of two pixels per record on the 10 M small triangles:
-                    // 40 of an item's 175 vector instructions)
-                    const TriSetup mine = make_setup(cur_t, true);
-                    q.pre.l03[tid] = mine.l03; q.pre.l13[tid] = mine.l13; q.pre.l23[tid] = mine.l23;
-                    q.pre.r1[tid] = mine.fast ? mine.r1 : 0.0f; q.pre.r2[tid] = mine.r2; q.pre.r3[tid] = mine.r3;
-                    q.pre.px_scan[tid] = incl_px - my_px;
-                    __syncthreads();
-                }
-            }
-            // next batch: issue its loads now, they complete under the sweeps
-            const uint32_t nxt = base + kBatch + tid;
-            cur_ok = tid < kBatch && nxt < end;
-            if (cur_ok) cur_ok = load_record(L, proj, G, nxt, cur_id, cur_t, cur_bx, cur_by);
-            // Per-pixel sweep: every pixel of every clipped box is one work item; thread t takes
-            // items t, t + 256, ...  All lanes work on a sample that lies in its box (a 4x4 block
-            // of a small box is mostly empty: 71 % of T-Rex 1024^2's block lanes were inside their
-            // box, 40-50 % on its busiest tiles, 35 % for the 10 M small triangles), and there is
-            // no per-group record walk.  The item's record comes from a two-level search of the
-            // prefix sums (most batches fit the first wavefront's 64 slots: then no wavefront
-            // selection and only log2 of the record count steps).
-            auto sweep_pixels = [&](const uint32_t *scan, const uint32_t *wo_, int total_) {
-                const int first_n = nrec <= 1 ? 1 : (nrec > 64 ? 64 : 1 << (32 - __clz(nrec - 1)));
-                for (int e = tid; e < total_; e += kThreads) {
-                    uint32_t i;
-                    int r;
-                    if (nrec <= 64) {
-                        int lo = 0;
-                        for (int n = first_n; n > 1;) {     // last slot with scan <= e
-                            const int half = n >> 1;
-                            if (scan[lo + half] <= (uint32_t)e) lo += half;
-                            n -= half;
-                        }
-                        r = lo;
-                        i = (uint32_t)e - scan[lo];
-                    } else {
-                        r = find_record(scan, wo_, e, i);
-                    }
-                    if constexpr (TS == 16) {
-                        const Rec16Regs R = load_rec16(&recs[r]);
-                        const uint32_t xy = __float_as_uint(R.c.z);
-                        const int bw = box_w(__float_as_uint(R.c.w));
-                        // kItemPixels samples per item — x-neighbours of one box row — share the
-                        // item's record search, its six LDS reads and its decode (a third of a
-                        // sample's instructions and most of an iteration's dependent LDS round
-                        // trips); a box width that is no multiple wastes part of an item per row.
-                        const int bwn = (bw + kItemPixels - 1) / kItemPixels;
-                        const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
-                        const int px0 = ((int)i - dy * bwn) * kItemPixels;
-                        const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
-                        unsigned long long *kp = &key[key_slot<TS>(x - X0, y - Y0)];
+        for (int j = 0; j < kItemPixels32; ++j) {
+            float n1, n2, n3;
+            numerators(st, x + j, y, n1, n2, n3);
+            unsigned long long k;
+            if (fragment_from(st, id, n1, n2, n3, true, k) && px0 + j < bw)
+                lds_key_min(&key[key_slot<TS>(x + j - X0, y - Y0)], k);
+        }
+        left -= bw != 0 ? 1 : 0;
+        px0 += kItemPixels32;
+        const bool row_done = px0 >= bw;
+        px0 = row_done ? 0 : px0;
+        dy += row_done ? 1 : 0;
+        const bool rec_done = dy >= bh;
+        dy = rec_done ? 0 : dy;
+        r += rec_done ? 1 + (int)packed_skip(pb) : 0;
+    }
+}
+
+// 32-pixel tiles, the whole list ONE batch of large records: the pixels' owners take the tile (owner_tile).
+template <bool CLEAR>
+CR_DEV void owner_path32(const Tile<32> &c, int nrec)
+{
+    CR_TILE_LOCALS(c);
+    // what depends on the triangle alone — the three denominators of mu.pyx:11-21 and
+    // their refined reciprocals (raster_math.h (2)) — once per record, by the record's
+    // thread, into the (unused) key plane: eight words per record
+    // — and which of the four wavefronts' bands of eight rows the triangle can touch at all
+    // (the exact rectangle test on box ∩ band, once per record instead of once per
+    // record and wavefront), with the signs of the denominators and the window flag
+    // in one word: a wavefront passes over a record that is not its business with
+    // one LDS read
+    float *pre = reinterpret_cast<float *>(key);
+    if (tid < nrec) {
+        const TriSetup st = make_setup(TriXYZ{q.x0[tid], q.y0[tid], q.z0[tid], q.x1[tid], q.y1[tid], q.z1[tid],
+                                               q.x2[tid], q.y2[tid], q.z2[tid]}, true);
+        const uint32_t bwh = packed_wh(q.box[tid]), bxy = packed_xy(q.box[tid], X0, Y0);
+        uint32_t flags = st.fast ? kOwnFast : 0u;
+        flags |= (uint32_t)(st.rej1 > 0.0f ? 1 : st.rej1 < 0.0f ? 2 : 0) << 5;
+        flags |= (uint32_t)(st.rej2 > 0.0f ? 1 : st.rej2 < 0.0f ? 2 : 0) << 7;
+        flags |= (uint32_t)(st.rej3 > 0.0f ? 1 : st.rej3 < 0.0f ? 2 : 0) << 9;
+        if (bwh != 0) {
+            const int bx0 = (int)(bxy & 0xFFFF), by0 = (int)(bxy >> 16);
+            const int bx1 = bx0 + box_w(bwh), by1 = by0 + box_h(bwh);
 #pragma unroll
-                        for (int j = 0; j < kItemPixels; ++j) {
-                            unsigned long long k;
-                            if (fragment16(R, x + j, y, k) && (j == 0 || px0 + j < bw)) lds_key_min(kp + j, k);
-                        }
-                    } else {
-                        const uint32_t xy = packed_xy(q.box[r], X0, Y0);
-                        const int bw = box_w(packed_wh(q.box[r]));
-                        const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r],
-                                       q.x2[r], q.y2[r], q.z2[r]};
-                        const uint32_t id = q.tri[r];
-                        // the item's samples share its record search, its twelve LDS reads, the nine
-                        // edge constants and the refined reciprocals (raster_math.h (2)): per sample
-                        // that was 150 vector instructions, a pair costs 175
-                        TriSetup st;
-                        {
-                            st.x0 = t.x0; st.y0 = t.y0; st.z0 = t.z0; st.x1 = t.x1; st.y1 = t.y1; st.z1 = t.z1;
-                            st.x2 = t.x2; st.y2 = t.y2; st.z2 = t.z2;
-                            st.l01 = t.x1 - t.x2; st.l02 = t.y1 - t.y2;
-                            st.l11 = t.x2 - t.x0; st.l12 = t.y2 - t.y0;
-                            st.l21 = t.x0 - t.x1; st.l22 = t.y0 - t.y1;
-                            st.l03 = q.pre.l03[r]; st.l13 = q.pre.l13[r]; st.l23 = q.pre.l23[r];
-                            st.r1 = q.pre.r1[r]; st.r2 = q.pre.r2[r]; st.r3 = q.pre.r3[r];
-                            st.fast = st.r1 != 0.0f;
-                            st.rej1 = st.rej2 = st.rej3 = 0.0f;
-                        }
-                        const int bwn = (bw + kItemPixels32 - 1) / kItemPixels32;
-                        // i / bwn for i < 1024, bwn <= 32: the approximate reciprocal is exact enough
-                        const int dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
-                        const int px0 = ((int)i - dy * bwn) * kItemPixels32;
-                        const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
-#pragma unroll
-                        for (int j = 0; j < kItemPixels32; ++j) {
-                            float n1, n2, n3;
-                            numerators(st, x + j, y, n1, n2, n3);
-                            unsigned long long k;
-                            if (fragment_from(st, id, n1, n2, n3, true, k) && (j == 0 || px0 + j < bw))
-                                lds_key_min(&key[key_slot<TS>(x + j - X0, y - Y0)], k);
-                        }
-                    }
-                }
-            };
-            // The same items — pairs of x-neighbours of the clipped boxes' rows — in RUNS: thread t takes
-            // items [t c, (t + 1) c) of the batch (c = ceil(total / 256)), finds the record of its first
-            // item by the search above ONCE and then walks: next pair of the row, next row, next record.
-            // Per item that is no search (6 dependent LDS reads and ~55 of ~230 vector instructions on
-            // batches of more than 64 records) and no division for the row; the record is re-read
-            // from LDS per item as before (registers: the 32-pixel kernel has none to spare), one round
-            // trip.  Lanes of a wavefront hold neighbouring records (consecutive LDS banks), every lane
-            // makes the same number of trips.
-            auto sweep_runs = [&](const uint32_t *wo_, int total_) {
-                const int chunk = (total_ + kThreads - 1) / kThreads;
-                int e = tid * chunk;
-                int left = (e + chunk < total_ ? e + chunk : total_) - e;       // items of this thread's run
-                if (left <= 0) return;
-                uint32_t i;
-                int r = find_record(q.pre.px_scan, wo_, e, i);
-                int dy, px0;             // the item within its record: row of the box, first pixel of the pair
-                {
-                    const int bwn = (box_w(packed_wh(q.box[r])) + kItemPixels32 - 1) / kItemPixels32;
-                    dy = (int)(((float)i + 0.5f) * __builtin_amdgcn_rcpf((float)bwn));
-                    px0 = ((int)i - dy * bwn) * kItemPixels32;
-                }
-                // ONE flat loop, its state stepped with selects: with `if (row done) { if (record done) ... }`
-                // the compiler turned the walk into three nested loops (pairs of a row, rows of a record,
-                // records) in which every lane waits for the wavefront's longest row and tallest box —
-                // twice the time.  Records without work are stepped over (packed_skip); the first slot of
-                // a wavefront's 64 may still be one: an idle trip.
-                while (left > 0) {
-                    const uint32_t pb = q.box[r];
-                    const uint32_t xy = packed_xy(pb, X0, Y0), wh = packed_wh(pb);
-                    const int bw = box_w(wh), bh = box_h(wh);
-                    const TriXYZ t{q.x0[r], q.y0[r], q.z0[r], q.x1[r], q.y1[r], q.z1[r], q.x2[r], q.y2[r], q.z2[r]};
-                    const uint32_t id = q.tri[r];
-                    TriSetup st;
-                    {
-                        st.x0 = t.x0; st.y0 = t.y0; st.z0 = t.z0; st.x1 = t.x1; st.y1 = t.y1; st.z1 = t.z1;
-                        st.x2 = t.x2; st.y2 = t.y2; st.z2 = t.z2;
-                        st.l01 = t.x1 - t.x2; st.l02 = t.y1 - t.y2;
-                        st.l11 = t.x2 - t.x0; st.l12 = t.y2 - t.y0;
-                        st.l21 = t.x0 - t.x1; st.l22 = t.y0 - t.y1;
-                        st.l03 = q.pre.l03[r]; st.l13 = q.pre.l13[r]; st.l23 = q.pre.l23[r];
-                        st.r1 = q.pre.r1[r]; st.r2 = q.pre.r2[r]; st.r3 = q.pre.r3[r];
-                        st.fast = st.r1 != 0.0f;
-                        st.rej1 = st.rej2 = st.rej3 = 0.0f;
-                    }
-                    const int x = (int)(xy & 0xFFFF) + px0, y = (int)(xy >> 16) + dy;
-#pragma unroll
-                    for (int j = 0; j < kItemPixels32; ++j) {
-                        float n1, n2, n3;
-                        numerators(st, x + j, y, n1, n2, n3);
-                        unsigned long long k;
-                        if (fragment_from(st, id, n1, n2, n3, true, k) && px0 + j < bw)
-                            lds_key_min(&key[key_slot<TS>(x + j - X0, y - Y0)], k);
-                    }
-                    left -= bw != 0 ? 1 : 0;
-                    px0 += kItemPixels32;
-                    const bool row_done = px0 >= bw;
-                    px0 = row_done ? 0 : px0;
-                    dy += row_done ? 1 : 0;
-                    const bool rec_done = dy >= bh;
-                    dy = rec_done ? 0 : dy;
-                    r += rec_done ? 1 + (int)packed_skip(pb) : 0;
-                }
-            };
-            if constexpr (TS == 32) {
-                // the whole list is this one batch of large records: the pixels' owners take it from here
-                if (base == beg && end - beg <= (uint32_t)kBatch && !small_by_pixel && !(dbg & 32768)) {
-                    // what depends on the triangle alone — the three denominators of mu.pyx:11-21 and
-                    // their refined reciprocals (raster_math.h (2)) — once per record, by the record's
-                    // thread, into the (unused) key plane: eight words per record
-                    // — and which of the four wavefronts' bands of eight rows the triangle can touch at all
-                    // (the exact rectangle test on box ∩ band, once per record instead of once per
-                    // record and wavefront), with the signs of the denominators and the window flag
-                    // in one word: a wavefront passes over a record that is not its business with
-                    // one LDS read
-                    float *pre = reinterpret_cast<float *>(key);
-                    if (tid < nrec) {
-                        const TriSetup st = make_setup(TriXYZ{q.x0[tid], q.y0[tid], q.z0[tid], q.x1[tid], q.y1[tid], q.z1[tid],
-                                                               q.x2[tid], q.y2[tid], q.z2[tid]}, true);
-                        const uint32_t bwh = packed_wh(q.box[tid]), bxy = packed_xy(q.box[tid], X0, Y0);
-                        uint32_t flags = st.fast ? kOwnFast : 0u;
-                        flags |= (uint32_t)(st.rej1 > 0.0f ? 1 : st.rej1 < 0.0f ? 2 : 0) << 5;
-                        flags |= (uint32_t)(st.rej2 > 0.0f ? 1 : st.rej2 < 0.0f ? 2 : 0) << 7;
-                        flags |= (uint32_t)(st.rej3 > 0.0f ? 1 : st.rej3 < 0.0f ? 2 : 0) << 9;
-                        if (bwh != 0) {
-                            const int bx0 = (int)(bxy & 0xFFFF), by0 = (int)(bxy >> 16);
-                            const int bx1 = bx0 + box_w(bwh), by1 = by0 + box_h(bwh);
-#pragma unroll
-                            for (int band = 0; band < 4; ++band) {
-                                const int ya = Y0 + 8 * band, yb = (ya + 8 < Y1) ? ya + 8 : Y1;
-                                if (by1 > ya && by0 < yb &&
-                                    !rect_surely_missed(st, bx0, bx1 - 1, by0 > ya ? by0 : ya, (by1 < yb ? by1 : yb) - 1))
-                                    flags |= 1u << band;
-                            }
-                        }
-                        float4 *o = reinterpret_cast<float4 *>(pre + 8 * tid);
-                        o[0] = make_float4(st.l03, st.l13, st.l23, __uint_as_float(flags));
-                        o[1] = make_float4(st.r1, st.r2, st.r3, 0.0f);
-                    }
-                    __syncthreads();
-                    if (L.addr32)
-                        owner_tile<CLEAR, uint32_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, zb, cb, nb, win,
-                                                    G.W, X0, Y0, X1, Y1);
-                    else
-                        owner_tile<CLEAR, size_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, zb, cb, nb, win,
-                                                  G.W, X0, Y0, X1, Y1);
-                    CR_STAMP(3);
-                    return;
-                }
-                if (base == beg) {
-                    init_keys();
-                    __syncthreads();
-                }
-            }
-            if constexpr (per_pixel) {
-                sweep_pixels(scan16, wo, total);
-            } else if (small_by_pixel) {
-                uint32_t wop[kThreads / 64 + 1];
-                wop[0] = 0;
-#pragma unroll
-                for (int w = 0; w < kThreads / 64; ++w) wop[w + 1] = wop[w] + q.wave_px[w];
-                // (item by item — thread t takes items t, t + 256, ... with a search per item — only as a
-                // development knob: the run-wise walk is faster on every workload once the key plane is
-                // swizzled, T-Rex 1024^2 pipelined +12 %, 10 M small triangles' raster launch -4 %)
-                const int items = (int)wop[kThreads / 64];
-#ifdef CRENDER_RUNS_MAX_AVG
-                if ((dbg & (1 << 30)) || items > CRENDER_RUNS_MAX_AVG * nrec) sweep_pixels(q.pre.px_scan, wop, items); else
-#else
-                if (dbg & (1 << 30)) sweep_pixels(q.pre.px_scan, wop, items); else
-#endif
-                sweep_runs(wop, items);
-            } else if (TS == 64 && ((total < 16 * nrec && !(dbg & 8192)) || (dbg & 128))) {
-                // Small records: each of the 16 lane groups takes one contiguous run of blocks,
-                // so a record is set up by (almost) one group only; tight loop, plain division.
-                const int chunk = (total + 15) >> 4;
-                int p = (tid >> 4) * chunk;
-                const int pend = (p + chunk < total) ? (p + chunk) : total;
-                if (p < pend) {
-                    uint32_t first;
-                    int r = find_record(q.big.blk_scan, wo, p, first);
-                    Work<TriXYZ> wk = load_work<TriXYZ>(q, r, X0, Y0);
-                    int b = (int)first;
-                    int by = (int)(((float)b + 0.5f) * (1.0f / (float)wk.nbx)), bx = b - by * wk.nbx;
-                    for (;;) {
-                        const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
-                        unsigned long long k;
-                        if (x < wk.bx1 && y < wk.by1 && fragment(wk.s, wk.id, x, y, k))
-                            lds_key_min(&key[key_slot<TS>(x - X0, y - Y0)], k);
-                        if (++p >= pend) break;
-                        if (++b < wk.nblk) {
-                            if (++bx == wk.nbx) { bx = 0; ++by; }
-                        } else {
-                            // p < pend guarantees a later record with blocks
-                            do { wk = load_work<TriXYZ>(q, ++r, X0, Y0); } while (wk.nblk == 0);
-                            b = bx = by = 0;
-                        }
-                    }
-                }
-            } else {
-                // Large records (>= 16 blocks on average).  A triangle fills at most half of its
-                // pixel box, so first a coarse pass (one LANE per 4x4 block) discards blocks that
-                // lie entirely outside one edge; the survivors are then swept (one 16-lane GROUP
-                // per block): each wavefront takes a contiguous quarter of them and its four
-                // groups consecutive survivors, so the four blocks a wavefront works on at a
-                // time are neighbours.  In the sweep, lanes whose sign test is certainly negative
-                // are dead before any division (skipped wave-wide when nobody is live,
-                // raster_math.h (1)); the divisions that remain use the hoisted reciprocal (2).
-                const bool allow_rej = !(dbg & 32), allow_fast = !(dbg & 64);
-                if constexpr (TS <= 32) {          // a record has at most 64 blocks: one mask word
-                    q.big.mask[tid] = 0;
-                    if constexpr (either) q.big.blk_scan[tid] = blk_excl;
-                    __syncthreads();
-                    // ---- coarse pass.  Exact: each numerator is monotone in X and in Y (every
-                    // rounding step is), so its extreme over the block sits on a corner; a block
-                    // goes only if all four corners are "surely outside" the SAME edge, which is
-                    // then true of every pixel in it (raster_math.h (1)).
-                    coarse_cull(q, wo, total, tid, X0, Y0, (dbg & 4096) != 0);
-                    __syncthreads();
-                    // survivors per record -> the same two-level prefix as the block counts
-                    const uint32_t mine = (uint32_t)__popcll(q.big.mask[tid]);
-                    const uint32_t inc = wave_incl_sum(mine);
-                    q.big.blk_scan[tid] = inc - mine;
-                    if (lane == 63) q.wave_blocks[wave] = inc;
-                    __syncthreads();
-#pragma unroll
-                    for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + q.wave_blocks[w];
-                    const int work = (int)wo[kThreads / 64];       // surviving blocks
-                    // the survivors are almost all partly or fully covered, so wave-wide
-                    // rejection would rarely fire: plain contiguous runs, one per lane group
-                    const int chunk = (work + 15) >> 4;
-                    int p = (tid >> 4) * chunk;
-                    const int pend = (p + chunk < work) ? (p + chunk) : work;
-                    if (p < pend) {
-                        uint32_t first;
-                        int r = find_record(q.big.blk_scan, wo, p, first);
-                        Work<TriSetup> wk = load_work<TriSetup>(q, r, X0, Y0);
-                        float inv_nbx = 1.0f / (float)wk.nbx;
-                        // the record's survivor mask with everything before the current block cleared
-                        unsigned long long m = q.big.mask[r];
-                        for (uint32_t i = 0; i < first; ++i) m &= m - 1;
-                        for (;;) {
-                            const int b = __ffsll((long long)m) - 1;
-                            const int by = (int)(((float)b + 0.5f) * inv_nbx), bx = b - by * wk.nbx;
-                            const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
-                            float n1, n2, n3;
-                            numerators(wk.s, x, y, n1, n2, n3);
-                            unsigned long long k;
-                            if (x < wk.bx1 && y < wk.by1 && fragment_from(wk.s, wk.id, n1, n2, n3, allow_fast, k))
-                                lds_key_min(&key[key_slot<TS>(x - X0, y - Y0)], k);
-                            if (++p >= pend) break;   // (p < pend guarantees another survivor)
-                            m &= m - 1;
-                            if (m == 0) {
-                                do { m = q.big.mask[++r]; } while (m == 0);
-                                wk = load_work<TriSetup>(q, r, X0, Y0);
-                                inv_nbx = 1.0f / (float)wk.nbx;
-                            }
-                        }
-                    }
-                } else {
-                    // 64-pixel tiles (up to 256 blocks per record): no cull, dense walk
-                    const int wchunk = (total + kThreads / 64 - 1) / (kThreads / 64);
-                    int p = wave * wchunk + ((tid >> 4) & 3);
-                    const int pend = ((wave + 1) * wchunk < total) ? ((wave + 1) * wchunk) : total;
-                    if (p < pend) {
-                        uint32_t first;
-                        int r = find_record(q.big.blk_scan, wo, p, first);
-                        Work<TriSetup> wk = load_work<TriSetup>(q, r, X0, Y0);
-                        int b = (int)first;
-                        float inv_nbx = 1.0f / (float)wk.nbx;
-                        for (;;) {
-                            const int by = (int)(((float)b + 0.5f) * inv_nbx), bx = b - by * wk.nbx;
-                            const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
-                            float n1, n2, n3;
-                            numerators(wk.s, x, y, n1, n2, n3);
-                            const bool live = x < wk.bx1 && y < wk.by1 &&
-                                              !(allow_rej && surely_outside(wk.s, n1, n2, n3));
-                            if (wave_any(live)) {   // wavefront-uniform
-                                unsigned long long k;
-                                if (live && fragment_from(wk.s, wk.id, n1, n2, n3, allow_fast, k))
-                                    lds_key_min(&key[key_slot<TS>(x - X0, y - Y0)], k);
-                            }
-                            p += 4;
-                            if (p >= pend) break;
-                            b += 4;
-                            if (b >= wk.nblk) {
-                                do {
-                                    b -= wk.nblk;
-                                    wk = load_work<TriSetup>(q, ++r, X0, Y0);
-                                } while (b >= wk.nblk);
-                                inv_nbx = 1.0f / (float)wk.nbx;
-                            }
-                        }
-                    }
-                }
+            for (int band = 0; band < 4; ++band) {
+                const int ya = Y0 + 8 * band, yb = (ya + 8 < Y1) ? ya + 8 : Y1;
+                if (by1 > ya && by0 < yb &&
+                    !rect_surely_missed(st, bx0, bx1 - 1, by0 > ya ? by0 : ya, (by1 < yb ? by1 : yb) - 1))
+                    flags |= 1u << band;
             }
         }
+        float4 *o = reinterpret_cast<float4 *>(pre + 8 * tid);
+        o[0] = make_float4(st.l03, st.l13, st.l23, __uint_as_float(flags));
+        o[1] = make_float4(st.r1, st.r2, st.r3, 0.0f);
     }
     __syncthreads();
+    if (L.addr32)
+        owner_tile<CLEAR, uint32_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, zb, cb, nb, win,
+                                    G.W, X0, Y0, X1, Y1);
+    else
+        owner_tile<CLEAR, size_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, zb, cb, nb, win,
+                                  G.W, X0, Y0, X1, Y1);
+    CR_STAMP(3);
+}
 
-    CR_STAMP(2);
+// 64-pixel tiles, small records: each of the 16 lane groups takes one contiguous run of blocks,
+// so a record is set up by (almost) one group only; tight loop, plain division.
+CR_DEV void walk64_small(const Tile<64> &c, const uint32_t *wo, int total)
+{
+    constexpr int TS = 64;
+    CR_TILE_LOCALS(c);
+    const int l = tid & 15, lx = l & 3, ly = l >> 2;
+    const int chunk = (total + 15) >> 4;
+    int p = (tid >> 4) * chunk;
+    const int pend = (p + chunk < total) ? (p + chunk) : total;
+    if (p < pend) {
+        uint32_t first;
+        int r = find_record(q.big.blk_scan, wo, p, first);
+        Work<TriXYZ> wk = load_work<TriXYZ>(q, r, X0, Y0);
+        int b = (int)first;
+        int by = (int)(((float)b + 0.5f) * (1.0f / (float)wk.nbx)), bx = b - by * wk.nbx;
+        for (;;) {
+            const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
+            unsigned long long k;
+            if (x < wk.bx1 && y < wk.by1 && fragment(wk.s, wk.id, x, y, k))
+                lds_key_min(&key[key_slot<TS>(x - X0, y - Y0)], k);
+            if (++p >= pend) break;
+            if (++b < wk.nblk) {
+                if (++bx == wk.nbx) { bx = 0; ++by; }
+            } else {
+                // p < pend guarantees a later record with blocks
+                do { wk = load_work<TriXYZ>(q, ++r, X0, Y0); } while (wk.nblk == 0);
+                b = bx = by = 0;
+            }
+        }
+    }
+}
+
+// Large records (>= 16 blocks on average).  A triangle fills at most half of its
+// pixel box, so first a coarse pass (one LANE per 4x4 block) discards blocks that
+// lie entirely outside one edge; the survivors are then swept (one 16-lane GROUP
+// per block): each wavefront takes a contiguous quarter of them and its four
+// groups consecutive survivors, so the four blocks a wavefront works on at a
+// time are neighbours.  In the sweep, lanes whose sign test is certainly negative
+// are dead before any division (skipped wave-wide when nobody is live,
+// raster_math.h (1)); the divisions that remain use the hoisted reciprocal (2).
+template <int TS>
+CR_DEV void sweep_blocks_culled(const Tile<TS> &c, uint32_t (&wo)[kThreads / 64 + 1], int total, uint32_t blk_excl)
+{
+    static_assert(TS <= 32, "a record has at most 64 blocks: one mask word");
+    CR_TILE_LOCALS(c);
+    const int l = tid & 15, lx = l & 3, ly = l >> 2;
+    [[maybe_unused]] const bool allow_rej = !(dbg & 32), allow_fast = !(dbg & 64);
+    q.big.mask[tid] = 0;
+    if constexpr (TS == 32) q.big.blk_scan[tid] = blk_excl;
+    __syncthreads();
+    // ---- coarse pass.  Exact: each numerator is monotone in X and in Y (every
+    // rounding step is), so its extreme over the block sits on a corner; a block
+    // goes only if all four corners are "surely outside" the SAME edge, which is
+    // then true of every pixel in it (raster_math.h (1)).
+    coarse_cull(q, wo, total, tid, X0, Y0, (dbg & 4096) != 0);
+    __syncthreads();
+    // survivors per record -> the same two-level prefix as the block counts
+    const uint32_t mine = (uint32_t)__popcll(q.big.mask[tid]);
+    const uint32_t inc = wave_incl_sum(mine);
+    q.big.blk_scan[tid] = inc - mine;
+    if (lane == 63) q.wave_blocks[wave] = inc;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + q.wave_blocks[w];
+    const int work = (int)wo[kThreads / 64];       // surviving blocks
+    // the survivors are almost all partly or fully covered, so wave-wide
+    // rejection would rarely fire: plain contiguous runs, one per lane group
+    const int chunk = (work + 15) >> 4;
+    int p = (tid >> 4) * chunk;
+    const int pend = (p + chunk < work) ? (p + chunk) : work;
+    if (p < pend) {
+        uint32_t first;
+        int r = find_record(q.big.blk_scan, wo, p, first);
+        Work<TriSetup> wk = load_work<TriSetup>(q, r, X0, Y0);
+        float inv_nbx = 1.0f / (float)wk.nbx;
+        // the record's survivor mask with everything before the current block cleared
+        unsigned long long m = q.big.mask[r];
+        for (uint32_t i = 0; i < first; ++i) m &= m - 1;
+        for (;;) {
+            const int b = __ffsll((long long)m) - 1;
+            const int by = (int)(((float)b + 0.5f) * inv_nbx), bx = b - by * wk.nbx;
+            const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
+            float n1, n2, n3;
+            numerators(wk.s, x, y, n1, n2, n3);
+            unsigned long long k;
+            if (x < wk.bx1 && y < wk.by1 && fragment_from(wk.s, wk.id, n1, n2, n3, allow_fast, k))
+                lds_key_min(&key[key_slot<TS>(x - X0, y - Y0)], k);
+            if (++p >= pend) break;   // (p < pend guarantees another survivor)
+            m &= m - 1;
+            if (m == 0) {
+                do { m = q.big.mask[++r]; } while (m == 0);
+                wk = load_work<TriSetup>(q, r, X0, Y0);
+                inv_nbx = 1.0f / (float)wk.nbx;
+            }
+        }
+    }
+}
+
+// 64-pixel tiles (up to 256 blocks per record), large records: no cull, dense walk
+CR_DEV void walk64_dense(const Tile<64> &c, const uint32_t *wo, int total)
+{
+    constexpr int TS = 64;
+    CR_TILE_LOCALS(c);
+    const int l = tid & 15, lx = l & 3, ly = l >> 2;
+    const bool allow_rej = !(dbg & 32), allow_fast = !(dbg & 64);
+    const int wchunk = (total + kThreads / 64 - 1) / (kThreads / 64);
+    int p = wave * wchunk + ((tid >> 4) & 3);
+    const int pend = ((wave + 1) * wchunk < total) ? ((wave + 1) * wchunk) : total;
+    if (p < pend) {
+        uint32_t first;
+        int r = find_record(q.big.blk_scan, wo, p, first);
+        Work<TriSetup> wk = load_work<TriSetup>(q, r, X0, Y0);
+        int b = (int)first;
+        float inv_nbx = 1.0f / (float)wk.nbx;
+        for (;;) {
+            const int by = (int)(((float)b + 0.5f) * inv_nbx), bx = b - by * wk.nbx;
+            const int x = wk.bx0 + (bx << 2) + lx, y = wk.by0 + (by << 2) + ly;
+            float n1, n2, n3;
+            numerators(wk.s, x, y, n1, n2, n3);
+            const bool live = x < wk.bx1 && y < wk.by1 &&
+                              !(allow_rej && surely_outside(wk.s, n1, n2, n3));
+            if (wave_any(live)) {   // wavefront-uniform
+                unsigned long long k;
+                if (live && fragment_from(wk.s, wk.id, n1, n2, n3, allow_fast, k))
+                    lds_key_min(&key[key_slot<TS>(x - X0, y - Y0)], k);
+            }
+            p += 4;
+            if (p >= pend) break;
+            b += 4;
+            if (b >= wk.nblk) {
+                do {
+                    b -= wk.nblk;
+                    wk = load_work<TriSetup>(q, ++r, X0, Y0);
+                } while (b >= wk.nblk);
+                inv_nbx = 1.0f / (float)wk.nbx;
+            }
+        }
+    }
+}
+
+template <int TS, bool CLEAR>
+CR_DEV void resolve_tile(const Tile<TS> &c, bool slotted)
+{
+    constexpr int kBatch = TS == 16 ? kBatch16 : kThreads;
+    CR_TILE_LOCALS(c);
     // resolve: every pixel of the rectangle is written at most once (exactly once if CLEAR).
     // A part's pixels are taken by the first wavefronts in rows of its own width.
     const int npx = quad >= 0 ? rw * (TS / 2) : TS * TS;
@@ -1484,6 +1357,271 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     }
     };
     if (L.addr32) resolve(uint32_t{}); else resolve(size_t{});
+}
+
+// Workgroup `b` of a raster launch (the kernels below hand in their LDS: k_frame runs binning
+// wavefronts of another frame in the same launch): picks its tile, queues the tile's list batch by
+// batch and hands each batch to the sweep that suits it, then resolves the pixels.
+template <int TS, bool CLEAR>
+CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict__ col,
+                        const float *__restrict__ nrm, const TileLists &L,
+                        float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
+                        int32_t *__restrict__ win, const Geom &G, int dbg_arg, int b,
+                        unsigned long long *key, unsigned char *qraw)
+{
+    Tile<TS> c{proj, col, nrm, L, zb, cb, nb, win, G, key, qraw, 0, 0, 0, 0, 0, TS, -1, 0u, 0u};
+#ifdef CRENDER_DEV_KNOBS
+    c.dbg = dbg_arg;
+#else
+    (void)dbg_arg;
+#endif
+#ifdef CRENDER_STAMPS
+    // frames of a swap chain stamp into a region of their slot (bits 24..26 of dbg_arg), 8192 workgroups each
+    c.stamp_base = ((size_t)((dbg_arg >> 24) & 7) * 8192 + blockIdx.x) * 16;
+#endif
+    CR_TILE_DBG(c);
+    CR_TILE_STAMPS(c);
+    [[maybe_unused]] WorkQueue &q = *reinterpret_cast<WorkQueue *>(qraw);                 // (TS != 16 only)
+    [[maybe_unused]] Rec16 *recs = reinterpret_cast<Rec16 *>(qraw);                       // (TS == 16 only)
+    [[maybe_unused]] uint32_t *scan16 = reinterpret_cast<uint32_t *>(qraw + sizeof(Rec16) * kBatch16);
+    [[maybe_unused]] uint32_t *wave16 = scan16 + kThreads;
+    constexpr int kBatch = TS == 16 ? kBatch16 : kThreads;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    // ---- which tile, and which part of it (grid = [order builder, if ordered][3 * hmax helpers][ntiles
+    // main workgroups, one tile each])
+    int tile, quad;
+    bool helper;
+    if (!pick_tile<TS, CLEAR>(c, b, b, tile, quad, helper)) return;
+    const int ty = G.ntx_magic ? (int)__umulhi((uint32_t)tile, G.ntx_magic) : tile / G.ntx;
+    const int tx = tile - ty * G.ntx;
+    int X0 = tx * TS, Y0 = G.y0 + ty * TS;
+    int X1 = (X0 + TS < G.W) ? (X0 + TS) : G.W;
+    int Y1 = (Y0 + TS < G.y1) ? (Y0 + TS) : G.y1;
+
+    CR_STAMP(0);
+#ifdef CRENDER_STAMPS
+    if (g_stamps && threadIdx.x == 0) {
+        g_stamps[stamp_base + 7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID
+        g_stamps[stamp_base + 8] = (unsigned long long)tile;
+        g_stamps[stamp_base + 10] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+    // the tile's triangle list: a run of the scanned index array, or (direct bins, offs == null)
+    // a fixed-capacity slab of entries whose fill count k_setup_wave left in count[tile]
+    uint32_t beg, end;
+    if (L.offs) {
+        beg = L.offs[tile];
+        end = L.offs[tile + 1];
+        if (end > L.capacity) end = L.capacity;
+        if (beg > end) beg = end;
+    } else {
+        const uint32_t n = L.count[tile];
+        beg = (uint32_t)tile * L.capacity;
+        end = beg + (n < L.capacity ? n : L.capacity);
+    }
+    if (!helper) {
+        if (L.heavy_flag && L.heavy_flag[tile]) quad = 0;
+        // the other parity's counter of this tile: zero for the next frame
+        if (tid == 0) L.count_next[tile] = 0;
+    }
+    int rw = TS;                 // width of this workgroup's rectangle in the key plane's terms
+    if (quad >= 0) {
+        constexpr int HS = TS / 2;
+        if (end - beg >= quad_at(TS)) {         // four quadrants
+            X0 += (quad & 1) * HS; Y0 += (quad >> 1) * HS;
+            if (X1 > X0 + HS) X1 = X0 + HS;
+            rw = HS;
+        } else {                                // two halves; parts 2 and 3 have nothing to do
+            if (quad >= 2) {
+                if (tid == 0) L.heavy_slots[b] = 0;
+                return;
+            }
+            Y0 += quad * HS;
+        }
+        if (Y1 > Y0 + HS) Y1 = Y0 + HS;
+        if (X1 < X0) X1 = X0;
+        if (Y1 < Y0) Y1 = Y0;
+    }
+    if (dbg & 1) end = beg;   // ablation: no coverage work (development build)
+
+    const bool work = beg != end && X0 < X1 && Y0 < Y1;     // (uniform over the workgroup)
+    if (!work) {
+        // nothing to rasterize here: the rectangle keeps its content, or (fused clear) becomes
+        // background — no key plane, no barriers
+        if (CLEAR && X0 < X1 && Y0 < Y1) clear_rect<TS>(zb, cb, nb, win, G.W, X0, Y0, X1, Y1, L.vec_clear && quad < 0, tid);
+        CR_STAMP(3);
+    } else {
+    // 16-pixel tiles with direct bins (at most 65536 triangles): a depth key's low word carries
+    // the triangle index in its high half as usual and, in its low half, where the record sits
+    // in LDS — batch and slot — so that the resolve takes the winner's edge constants from there
+    const bool slotted = TS == 16 && !L.offs;
+    // first batch of the tile's list straight into registers
+    uint32_t cur_id = 0, cur_bx = 0, cur_by = 0;
+    TriXYZ cur_t{};
+    bool cur_ok = tid < kBatch && beg + tid < end;
+    if (cur_ok) cur_ok = load_record(L, proj, G, beg + tid, cur_id, cur_t, cur_bx, cur_by);
+
+    c.X0 = X0; c.Y0 = Y0; c.X1 = X1; c.Y1 = Y1; c.rw = rw; c.quad = quad; c.beg = beg; c.end = end;
+    // (32-pixel tiles: the keys once it is known that the tile is not the pixel owners', see below)
+    if constexpr (TS != 32) init_keys<TS, CLEAR>(c);
+    CR_STAMP(1);
+#ifdef CRENDER_STAMPS
+    if (g_stamps && tid == 0) {
+        g_stamps[stamp_base + 4] = end - beg;
+        g_stamps[stamp_base + 9] = (unsigned long long)(quad + 1);
+    }
+#endif
+
+    for (uint32_t base = beg; base < end; base += kBatch) {
+        // ---- queue this batch: one record per thread, slot = thread index --------------
+        uint32_t box_xy = 0, box_wh = 0;
+        if (cur_ok) {
+            int xl = (int)(cur_bx & 0xFFFF), xr = (int)(cur_bx >> 16);
+            int yt = (int)(cur_by & 0xFFFF), yb = (int)(cur_by >> 16);
+            if (xl < X0) xl = X0;
+            if (xr > X1) xr = X1;
+            if (yt < Y0) yt = Y0;
+            if (yb > Y1) yb = Y1;
+            if (xl < xr && yt < yb) {
+                box_xy = (uint32_t)xl | ((uint32_t)yt << 16);
+                box_wh = (uint32_t)(xr - xl) | ((uint32_t)(yb - yt) << 16);
+                // A large triangle's pixel box covers about twice its area: a good part of the
+                // entries of a frame of large triangles (bunny 4096^2: 8 per tile) name tiles the
+                // triangle never touches.  Exact test on (box ∩ tile); not worth its ~80
+                // instructions for a small box.
+                if (TS >= 32 && (xr - xl) * (yb - yt) >= 256 &&
+                    rect_surely_missed(make_setup(cur_t, false), xl, xr - 1, yt, yb - 1))
+                    box_wh = 0;
+            }
+        }
+        const uint32_t key_low = slotted ? ((0xFFFFu - (cur_id & 0xFFFFu)) << 16) | ((((base - beg) / kBatch) & 0xFFu) << 8) | (uint32_t)tid
+                                         : 0xFFFFFFFEu - cur_id;
+#ifdef CRENDER_STAMPS
+        if (base == beg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CR_STAMP(5); }
+#endif
+        if constexpr (TS == 16) {
+            // a short last batch goes pixel-parallel
+            const uint32_t left = end - base;
+            const uint32_t pix_max = (dbg >> 16) & 0xFF ? (uint32_t)((dbg >> 16) & 0xFF) - 1u : kPixelPathRecords;
+            if (left <= pix_max) {
+                pixel_path16(c, left, base == beg, cur_t, key_low, box_xy, box_wh);
+                cur_ok = false;
+                continue;   // (this was the list's last batch)
+            }
+        }
+        // 16-pixel tiles: the work is flattened per PIXEL of the clipped boxes, not per block
+        // (see the sweep below); elsewhere per 16-pixel block
+        constexpr bool per_pixel = TS == 16;   // always the per-pixel sweep
+        constexpr bool either = TS == 32;      // counted both ways, the batch picks its sweep
+        // wave-inclusive scan of the work counts
+        // (per-pixel work is counted in ITEMS of kItemPixels / kItemPixels32 x-neighbours of a box row)
+        const uint32_t my_px = (uint32_t)(((box_w(box_wh) + kItemPixels32 - 1) / kItemPixels32) * box_h(box_wh));
+        // (16-pixel tiles: an item is a PAIR of x-neighbours of a box row, see the sweep)
+        const uint32_t my_blocks = per_pixel ? (uint32_t)(((box_w(box_wh) + kItemPixels - 1) / kItemPixels) * box_h(box_wh))
+                                             : (uint32_t)blocks_of(box_wh);
+        const uint32_t incl = wave_incl_sum(my_blocks);
+        uint32_t incl_px = my_px;
+        if constexpr (either) incl_px = wave_incl_sum(my_px);
+        // previous batch's sweeps must be over before the queue is overwritten (the first batch has
+        // none before it: the barrier behind the queue orders the key initialisation too)
+        if (base != beg) __syncthreads();
+        if constexpr (TS == 16) {
+            if (tid < kBatch) put_rec16(&recs[tid], cur_t, key_low, box_xy, box_wh);
+            scan16[tid] = incl - my_blocks;
+            if (lane == 63) wave16[wave] = incl;
+        } else {
+            q.x0[tid] = cur_t.x0; q.y0[tid] = cur_t.y0; q.z0[tid] = cur_t.z0;
+            q.x1[tid] = cur_t.x1; q.y1[tid] = cur_t.y1; q.z1[tid] = cur_t.z1;
+            q.x2[tid] = cur_t.x2; q.y2[tid] = cur_t.y2; q.z2[tid] = cur_t.z2;
+            q.tri[tid] = cur_id;
+            {
+                const unsigned long long live = __builtin_amdgcn_ballot_w64(box_wh != 0);
+                const unsigned long long after = lane == 63 ? 0ull : live >> (lane + 1);
+                const uint32_t skip = after ? (uint32_t)__builtin_ctzll(after) : (uint32_t)(63 - lane);
+                q.box[tid] = pack_box(box_xy, box_wh, X0, Y0) | (skip << 26);
+            }
+            if constexpr (!either) q.big.blk_scan[tid] = incl - my_blocks;     // (32-pixel tiles: once the sweep is chosen)
+            if (lane == 63) q.wave_blocks[wave] = incl;
+            if constexpr (either) {
+                if (lane == 63) q.wave_px[wave] = incl_px;
+            }
+        }
+        __syncthreads();  // queue complete
+#ifdef CRENDER_STAMPS
+        if (base == beg) CR_STAMP(6);
+#endif
+
+        // ---- sweep: the batch's work items, flattened and split evenly -------------------------
+        {
+            uint32_t wo[kThreads / 64 + 1];
+            wo[0] = 0;
+#pragma unroll
+            for (int w = 0; w < kThreads / 64; ++w) wo[w + 1] = wo[w] + (TS == 16 ? wave16[w] : q.wave_blocks[w]);
+            const int total = (int)wo[kThreads / 64];
+            const int nrec = (int)((end - base) < (uint32_t)kBatch ? (end - base) : (uint32_t)kBatch);
+            const uint32_t blk_excl = incl - my_blocks;
+            bool small_by_pixel = false;    // 32-pixel tiles: small records go per pixel too
+            if constexpr (either) small_by_pixel = total < 16 * nrec && !(dbg & 8192);
+            if constexpr (either) {
+                if (small_by_pixel) {
+                    // every record's thread works out, ONCE, what an item of its record would otherwise
+                    // work out again (9 items of two pixels per record on the 10 M small triangles:
+                    // 40 of an item's 175 vector instructions)
+                    const TriSetup mine = make_setup(cur_t, true);
+                    q.pre.l03[tid] = mine.l03; q.pre.l13[tid] = mine.l13; q.pre.l23[tid] = mine.l23;
+                    q.pre.r1[tid] = mine.fast ? mine.r1 : 0.0f; q.pre.r2[tid] = mine.r2; q.pre.r3[tid] = mine.r3;
+                    q.pre.px_scan[tid] = incl_px - my_px;
+                    __syncthreads();
+                }
+            }
+            // next batch: issue its loads now, they complete under the sweeps
+            const uint32_t nxt = base + kBatch + tid;
+            cur_ok = tid < kBatch && nxt < end;
+            if (cur_ok) cur_ok = load_record(L, proj, G, nxt, cur_id, cur_t, cur_bx, cur_by);
+            if constexpr (TS == 32) {
+                // the whole list is this one batch of large records: the pixels' owners take it from here
+                if (base == beg && end - beg <= (uint32_t)kBatch && !small_by_pixel && !(dbg & 32768)) {
+                    owner_path32<CLEAR>(c, nrec);
+                    return;
+                }
+                if (base == beg) {
+                    init_keys<TS, CLEAR>(c);
+                    __syncthreads();
+                }
+            }
+            if constexpr (per_pixel) {
+                sweep_items<TS>(c, scan16, wo, total, nrec);
+            } else if (small_by_pixel) {
+                if constexpr (TS == 32) {
+                    uint32_t wop[kThreads / 64 + 1];
+                    wop[0] = 0;
+#pragma unroll
+                    for (int w = 0; w < kThreads / 64; ++w) wop[w + 1] = wop[w] + q.wave_px[w];
+                    // (item by item — thread t takes items t, t + 256, ... with a search per item — only as a
+                    // development knob: the run-wise walk is faster on every workload once the key plane is
+                    // swizzled, T-Rex 1024^2 pipelined +12 %, 10 M small triangles' raster launch -4 %)
+                    const int items = (int)wop[kThreads / 64];
+#ifdef CRENDER_RUNS_MAX_AVG
+                    if ((dbg & (1 << 30)) || items > CRENDER_RUNS_MAX_AVG * nrec) sweep_items<TS>(c, q.pre.px_scan, wop, items, nrec); else
+#else
+                    if (dbg & (1 << 30)) sweep_items<TS>(c, q.pre.px_scan, wop, items, nrec); else
+#endif
+                    sweep_runs32(c, wop, items);
+                }
+            } else if constexpr (TS == 64) {
+                if ((total < 16 * nrec && !(dbg & 8192)) || (dbg & 128)) walk64_small(c, wo, total);
+                else walk64_dense(c, wo, total);
+            } else {
+                sweep_blocks_culled<TS>(c, wo, total, blk_excl);
+            }
+        }
+    }
+    __syncthreads();
+
+    CR_STAMP(2);
+    resolve_tile<TS, CLEAR>(c, slotted);
     CR_STAMP(3);
 #ifdef CRENDER_STAMPS
     if (g_stamps && threadIdx.x == 0) g_stamps[stamp_base + 11] = __builtin_amdgcn_s_memtime();
