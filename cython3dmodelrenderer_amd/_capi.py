@@ -34,6 +34,7 @@ SIGNATURES = {
     "crender_plan_destroy": (None, [_vp]),
     "crender_plan_last_bin_usage": (_i32, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "crender_plan_last_frame_direct": (_i32, [_vp]),
+    "crender_plan_last_frame_binning": (_i32, [_vp]),
     "crender_plan_frame_ticket": (C.c_uint64, [_vp]),
     "crender_plan_poll_bin_usage": (_i32, [_vp, C.c_uint64, C.POINTER(_i64), C.POINTER(_i64)]),
     "crender_plan_set_light": (_i32, [_vp, _f32p]),

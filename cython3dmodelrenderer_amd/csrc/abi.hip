@@ -59,6 +59,12 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
         L.direct_cap = kDirectBinBytes / (int64_t)sizeof(BinEntry) / L.g.ntiles;
         if (L.direct_cap > 1024) L.direct_cap = 1024;
     }
+    L.pair_cap = 0;
+    if (L.direct_cap == 0 && max_T > 0) {
+        int64_t pc = (3 * max_T / L.g.ntiles + 64 + 63) / 64 * 64;
+        if (pc > 8192) pc = 8192;
+        if (pc * (int64_t)sizeof(uint2) * L.g.ntiles <= kPairBinBytes) L.pair_cap = pc;
+    }
     // heavy tiles are split with direct bins only (the small-frame regime, where a single tile's
     // latency sets the end of the launch): on 16-pixel tiles and — for frames rendered alone on the
     // swap chain's 32-pixel plans, whose 300 covered workgroups would leave most of 256 CUs idle — on
@@ -86,6 +92,7 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
     // (8 bytes per list entry: with a triangle order the entries are (position, caller's index) pairs)
     L.off_entries = o; o = align_up(o + sizeof(uint2) * (size_t)cap);
     L.off_direct = o;  o = align_up(o + sizeof(BinEntry) * (size_t)L.g.ntiles * (size_t)L.direct_cap);
+    L.off_pairbins = o; o = align_up(o + sizeof(uint2) * (size_t)L.g.ntiles * (size_t)L.pair_cap);
     L.total = o;
     return true;
 }
@@ -120,15 +127,18 @@ int tile_frame(crender_plan *plan, bool project, const float *d_tri, const float
 }
 
 // What the header words of a frame mean (crender_plan_last_bin_usage, crender_plan_poll_bin_usage).
-void usage_figures(crender_plan *plan, bool direct, uint32_t h0, uint32_t h1, uint32_t h4, int64_t *needed,
+void usage_figures(crender_plan *plan, int mode, uint32_t h0, uint32_t h1, uint32_t h4, int64_t *needed,
                    int64_t *capacity)
 {
-    if (direct) {
-        // direct bins: per-tile figures.  h1 is sticky: the longest list that did not fit
+    if (mode != 0) {
+        // direct bins / pair bins: per-tile figures.  h1 is sticky: the longest list that did not fit
         // (0xFFFFFFFF = a triangle spans too many tiles).  On overflow this plan switches to
         // the count / scan / fill path for good; the caller renders the frame again.
-        const int64_t cap = plan->L.direct_cap;
-        if (h1 > (uint32_t)cap) plan->direct_ok = false;  // h1 stays set: the answer is repeatable
+        const int64_t cap = mode == 1 ? plan->L.direct_cap : plan->L.pair_cap;
+        if (h1 > (uint32_t)cap) {                          // h1 stays set: the answer is repeatable
+            if (mode == 1) plan->direct_ok = false;
+            else plan->pairbins_ok = false;
+        }
         if (needed) *needed = h1 > (uint32_t)cap ? (int64_t)h1 : 0;
         if (capacity) *capacity = cap;
         return;
@@ -270,7 +280,7 @@ int crender_plan_last_bin_usage(crender_plan *plan, void *stream, int64_t *neede
     hipStream_t s = static_cast<hipStream_t>(stream);
     CR_HIP(hipMemcpyAsync(const_cast<uint32_t *>(h), plan->hdr(), 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     CR_HIP(hipStreamSynchronize(s));
-    usage_figures(plan, plan->last_frame_direct, h[0], h[1], h[4], needed, capacity);
+    usage_figures(plan, plan->last_frame_direct ? 1 : plan->last_frame_pairbins ? 2 : 0, h[0], h[1], h[4], needed, capacity);
     return CRENDER_OK;
 }
 
@@ -287,7 +297,7 @@ int crender_plan_poll_bin_usage(crender_plan *plan, uint64_t ticket, int64_t *ne
     // the record is ONE aligned 16-byte store of the launch: whole, or not there yet
     const uint32_t seq = __atomic_load_n(rec, __ATOMIC_ACQUIRE);
     if (seq != (uint32_t)ticket) return CRENDER_EBUSY;       // (not an error: no text)
-    usage_figures(plan, plan->usage_direct[slot], rec[1], rec[2], rec[3], needed, capacity);
+    usage_figures(plan, plan->usage_mode[slot], rec[1], rec[2], rec[3], needed, capacity);
     return CRENDER_OK;
 }
 
@@ -316,7 +326,12 @@ int crender_plan_set_light(crender_plan *plan, const float *light3)
 
 int crender_plan_last_frame_direct(crender_plan *plan)
 {
-    return plan && plan->last_frame_direct ? 1 : 0;
+    return plan && (plan->last_frame_direct || plan->last_frame_pairbins) ? 1 : 0;
+}
+
+int crender_plan_last_frame_binning(crender_plan *plan)
+{
+    return !plan ? 0 : plan->last_frame_direct ? 1 : plan->last_frame_pairbins ? 2 : 0;
 }
 
 int crender_raster(crender_plan *plan, const float *d_tri_proj, const float *d_col, const float *d_nrm,

@@ -9,6 +9,10 @@
 // parity with the reference depends on them.
 #include "plan.h"
 
+#ifndef CRENDER_BIN_PER
+#define CRENDER_BIN_PER 1
+#endif
+
 using namespace crender_detail;
 
 namespace {
@@ -211,6 +215,139 @@ __global__ __launch_bounds__(kWave) void k_count_wave(const float *__restrict__ 
         const int dy = (int)(((float)i + 0.5f) * rbw);              // exact: i < 2^22
         if (c) atomicAdd(&count[(Y0 + dy) * G.ntx + X0 + (i - dy * bw)], c);
     }
+}
+
+// ---- pair bins: large scenes binned in ONE pass --------------------------------------------------
+// k_count_wave's front (project, cull, pixel box, tile range, the projected vertices out) and k_fill_wave's
+// back (entries per tile in an LDS histogram over the wavefront's tile bounding box, one returning atomic
+// per touched tile, LDS cursors hand out the slots) in one wavefront — against fixed-capacity per-tile
+// slabs instead of scanned lists, so that neither the count pass's tile ranges (8 bytes per triangle
+// written and read again) nor the scan nor a second pass over the triangles exist.  Entries are
+// (position, caller's index) pairs (the position itself without a triangle order).  10 M small triangles:
+// k_count_wave 0.152 + k_scan 0.015 + k_fill_wave 0.087 ms -> this kernel alone.  A list that outgrows its
+// slab is reported like an overflow of the direct bins (hdr[1], sticky) and the plan returns to the three passes.
+// Groups of 64 triangles a wavefront takes through the chain together.  One: more groups lengthen the runs
+// of neighbouring positions in the lists (the raster launch gathers its records faster: 0.559 / 0.552 / 0.524 ms
+// with 1 / 2 / 4) but slow this pass down by more (0.176 / 0.195 / 0.279 ms; profiles/r05/ab_pair_bins_synth10m.txt).
+constexpr int kBinPer = CRENDER_BIN_PER;
+template <int TS, bool PROJECT>
+__global__ __launch_bounds__(kWave) void k_bin_wave(const float *__restrict__ tri_in,
+                                                    const float *__restrict__ nrm,
+                                                    const float *__restrict__ nz3,
+                                                    const uint32_t *__restrict__ orig_of,
+                                                    float *__restrict__ proj_out,
+                                                    uint32_t *__restrict__ count,
+                                                    uint2 *__restrict__ pairs, uint32_t cap,
+                                                    uint32_t *__restrict__ hdr, int64_t T,
+                                                    ProjConst P, Geom G)
+{
+    __shared__ __attribute__((aligned(16))) float sv[kBinPer * kWave * 9];
+    __shared__ uint32_t hist[kWaveHistTiles];
+    __shared__ uint32_t orig[kBinPer * kWave];            // (any lane writes any owner's entry)
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * (kWave * kBinPer);
+    const int n = (int)((T - b0) < kWave * kBinPer ? (T - b0) : kWave * kBinPer);
+    stage_in<kWave>(tri_in + b0 * 9, sv, n * 9);
+#pragma unroll
+    for (int i = 0; i < kWaveHistTiles / kWave; ++i) hist[i * kWave + lane] = 0;   // (while the inputs are on their way)
+    float nz[kBinPer][3];                          // .pyx:202 looks at the normals' z only
+#pragma unroll
+    for (int p = 0; p < kBinPer; ++p) {
+        const int k = p * kWave + lane;
+        nz[p][0] = nz[p][1] = nz[p][2] = 0.0f;
+        if (k < n) {
+            if (nz3) {          // the components apart (crender_plan_set_normal_z): 12 contiguous bytes per triangle
+                const float *nn = nz3 + (b0 + k) * 3;
+                nz[p][0] = nn[0]; nz[p][1] = nn[1]; nz[p][2] = nn[2];
+            } else {
+                const float *nn = nrm + (b0 + k) * 9;
+                nz[p][0] = nn[2]; nz[p][1] = nn[5]; nz[p][2] = nn[8];
+            }
+            orig[k] = orig_of ? orig_of[b0 + k] : (uint32_t)(b0 + k);
+        }
+    }
+    __syncthreads();
+    uint2 r[kBinPer];
+    int X0 = 0x7FFFFFFF, X1 = -1, Y0 = 0x7FFFFFFF, Y1 = -1;
+#pragma unroll
+    for (int p = 0; p < kBinPer; ++p) {
+        const int k = p * kWave + lane;
+        r[p] = make_uint2(kNoTiles, 0);
+        if (k < n) {
+            float *v = sv + k * 9;
+            float a[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a[i] = v[i];
+            if (PROJECT) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) project_vertex(P, a + 3 * c);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) v[i] = a[i];
+            }
+            const TriXYZ t{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]};
+            if (!backface(nz[p][0], nz[p][1], nz[p][2])) r[p] = tile_range<TS>(t, G);
+        }
+        if (r[p].x != kNoTiles) {
+            const int x0 = r[p].x & 0xFFFF, x1 = r[p].x >> 16, y0 = r[p].y & 0xFFFF, y1 = r[p].y >> 16;
+            X0 = x0 < X0 ? x0 : X0; X1 = x1 > X1 ? x1 : X1; Y0 = y0 < Y0 ? y0 : Y0; Y1 = y1 > Y1 ? y1 : Y1;
+        }
+    }
+    wave_box(X0, X1, Y0, Y1);
+    __syncthreads();
+    if (PROJECT) stage_out<kWave>(proj_out + b0 * 9, sv, n * 9);
+    if (X1 < 0) return;     // nothing to bin (uniform)
+    auto put = [&](uint32_t tile, uint32_t slot, int owner) {      // owner: 0 .. kBinPer * 64 - 1
+        if (slot < cap) pairs[(size_t)tile * cap + slot] = make_uint2((uint32_t)(b0 + owner), orig[owner]);
+    };
+    const int bw = X1 - X0 + 1, area = bw * (Y1 - Y0 + 1);
+    if (area > kWaveHistTiles) {
+        // (large triangles: the wavefront's box exceeds the histogram) pair by pair
+#pragma unroll
+        for (int p = 0; p < kBinPer; ++p)
+            for_each_tile(r[p], (uint32_t)(p * kWave + lane), G.ntx, [&](int tile, uint32_t owner) {
+                const uint32_t slot = atomicAdd(&count[tile], 1u);
+                if (slot >= cap) atomicMax(&hdr[1], slot + 1u);
+                put((uint32_t)tile, slot, (int)owner);
+            });
+        return;
+    }
+#pragma unroll
+    for (int p = 0; p < kBinPer; ++p)
+        for_each_tile_xy(r[p], [&](int tx, int ty, int) { atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u); });
+    __syncthreads();
+    {
+        constexpr int kRounds = kWaveHistTiles / kWave;
+        const float rbw = 1.0f / (float)bw;
+        uint32_t c[kRounds], t[kRounds], base[kRounds];
+        const int nr = (area + kWave - 1) / kWave;      // rounds that have tiles at all (uniform; mostly 1)
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            c[k] = 0u; t[k] = 0u;
+            if (k < nr) {
+                const int i = k * kWave + lane;
+                c[k] = i < area ? hist[i] : 0u;
+                const int dy = (int)(((float)i + 0.5f) * rbw);          // exact: i < 2^22
+                t[k] = (uint32_t)((Y0 + dy) * G.ntx + X0 + (i - dy * bw));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k)                            // all in flight together
+            base[k] = c[k] ? atomicAdd(&count[t[k]], c[k]) : 0u;
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            if (c[k]) {
+                hist[k * kWave + lane] = base[k];
+                if (base[k] + c[k] > cap) atomicMax(&hdr[1], base[k] + c[k]);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < kBinPer; ++p)
+        for_each_tile_xy(r[p], [&](int tx, int ty, int owner) {
+            const uint32_t slot = atomicAdd(&hist[(ty - Y0) * bw + (tx - X0)], 1u);
+            put((uint32_t)(ty * G.ntx + tx), slot, p * kWave + owner);
+        });
 }
 
 // The fill pass in the same shape: (A) the wavefront's entries per tile in LDS, (B) one returning
@@ -479,7 +616,11 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
     // triangles can be expected to share tiles — a mesh, or a large model kept in tile-coherent
     // order; a large triangle soup in arbitrary order keeps the block histograms.
     const bool wave_scan = (plan->orig_of != nullptr || T < kWaveScanBelow) && !(dbg & 4);
-    plan->last_frame_pairs = !direct && wave_scan && plan->orig_of != nullptr && T > 0;
+    // large scenes: ONE binning pass into fixed-capacity slabs of (position, index) pairs (k_bin_wave)
+    const bool pairbins = !direct && wave_scan && T > 0 && L.pair_cap > 0 && plan->pairbins_ok &&
+                          !(flags & CRENDER_NO_DIRECT_BINS) && !(dbg & 16);
+    plan->last_frame_pairbins = pairbins;
+    plan->last_frame_pairs = pairbins || (!direct && wave_scan && plan->orig_of != nullptr && T > 0);
     if (T > 0 && direct) {
         // direct bins: one wavefront per 64 triangles
         HeavyReg hv;
@@ -508,6 +649,15 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
                                plan->proj(), count, plan->direct(), (uint32_t)L.direct_cap, plan->hdr(),
                                hv, T, P, G);
         CR_LAUNCH_CHECK("k_setup_wave");
+    } else if (pairbins) {
+        const unsigned nwg = (unsigned)((T + kWave * kBinPer - 1) / (kWave * kBinPer));
+        if (project)
+            hipLaunchKernelGGL((k_bin_wave<TS, true>), dim3(nwg), dim3(kWave), 0, s, d_tri, d_nrm, plan->normal_z, plan->orig_of,
+                               plan->proj(), count, plan->pairbins(), (uint32_t)L.pair_cap, plan->hdr(), T, P, G);
+        else
+            hipLaunchKernelGGL((k_bin_wave<TS, false>), dim3(nwg), dim3(kWave), 0, s, d_tri, d_nrm, plan->normal_z, plan->orig_of,
+                               plan->proj(), count, plan->pairbins(), (uint32_t)L.pair_cap, plan->hdr(), T, P, G);
+        CR_LAUNCH_CHECK("k_bin_wave");
     } else if (T > 0 && wave_scan) {
         const unsigned nwg = (unsigned)((T + kWave - 1) / kWave);
         if (project)
@@ -540,7 +690,7 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
 #undef CR_SETUP
         CR_LAUNCH_CHECK("k_setup");
     }
-    if (!direct) {
+    if (!direct && !pairbins) {
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, count, plan->offs(), plan->hdr(),
                            G.ntiles);
         CR_LAUNCH_CHECK("k_scan");

@@ -16,11 +16,12 @@ struct Layout {
     int64_t max_T;
     int64_t capacity;
     int64_t direct_cap;   // entries per tile of the direct bins, 0 = scene too large for them
+    int64_t pair_cap;     // entries per tile of the PAIR bins (large scenes binned in one pass, k_bin_wave), 0 = none
     int hmax;             // helper triples of a raster launch (heavy tiles split in four), 0 = none
     bool ordered;         // raster launches leave a dispatch order for the next one (build_order)
     size_t count_stride;  // u32 words between the two parities of the per-tile counters
     size_t off_hdr, off_count, off_hflag, off_hslots, off_hint, off_order, off_grouped, off_offs,
-           off_trange, off_proj, off_entries, off_direct, total;
+           off_trange, off_proj, off_entries, off_direct, off_pairbins, total;
 };
 constexpr int kUsageRing = 8;
 constexpr int kOrderMaxTiles = 8192;   // ordered dispatch: the builder keeps one byte per tile in the batch queue's LDS
@@ -32,6 +33,11 @@ constexpr int kMaxHeavyHelped = 128;   // +384 workgroups per raster launch (9 %
 constexpr int64_t kDirectMaxTriangles = 1 << 16;
 constexpr int kDirectMaxTiles = 1 << 16;    // beyond: count / scan / fill
 constexpr int64_t kDirectBinBytes = 512ll << 20;   // per-tile capacity = this budget / 48 B / tiles, <= 1024
+// Pair bins (scenes beyond the direct bins): fixed-capacity per-tile slabs of 8-byte (position, index) entries
+// that ONE binning pass appends to (k_bin_wave) — no count pass, no scan, no fill pass.  Sized at three
+// times the mean list (entries per triangle ~ 1.3), within 64 .. 8192 entries and kPairBinBytes in all; a
+// frame that does not fit reports so like the direct bins and the plan goes back to count / scan / fill.
+constexpr int64_t kPairBinBytes = 2048ll << 20;
 bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int tile, Layout &L);
 
 }  // namespace crender_detail
@@ -48,7 +54,9 @@ struct crender_plan {
     int timed_frames = 0;
     bool direct_ok = true;        // cleared once a frame overflowed the direct bins
     bool last_frame_direct = false;
-    bool last_frame_pairs = false;    // its list entries are (position, caller's index) pairs (k_fill_wave<true>)
+    bool last_frame_pairs = false;    // its list entries are (position, caller's index) pairs (k_fill_wave<true>, k_bin_wave)
+    bool pairbins_ok = true;          // cleared once a frame overflowed the pair bins
+    bool last_frame_pairbins = false; // binned in ONE pass into fixed-capacity per-tile slabs of pairs (k_bin_wave)
     int64_t last_T = -1;          // triangle count of the last bin pass (crender_draw must match)
     // The per-tile counters exist twice.  Frame f bins into parity f & 1 and its raster pass
     // zeroes the OTHER parity for frame f + 1, so no raster workgroup ever writes a counter that
@@ -74,7 +82,7 @@ struct crender_plan {
     uint32_t *usage = nullptr;            // [kUsageRing + 2][4] (the last two: staging of the blocking query)
     uint32_t *usage_dev = nullptr;        // the same memory as the device addresses it
     uint64_t ticket = 0;                  // raster launches so far: the last frame's number
-    bool usage_direct[kUsageRing] = {};   // the frame of each record went through the direct bins
+    unsigned char usage_mode[kUsageRing] = {};   // how the frame of each record was binned: 0 scan, 1 direct bins, 2 pair bins
     uint32_t *hint(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_hint) + 4 * k; }
     uint32_t *order(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_order) + (size_t)k * L.g.ntiles; }
     unsigned char *grouped(int k) const { return ws + L.off_grouped + (size_t)k * L.g.ntiles; }
@@ -87,6 +95,7 @@ struct crender_plan {
     float *proj() const { return reinterpret_cast<float *>(ws + L.off_proj); }
     uint32_t *entries() const { return reinterpret_cast<uint32_t *>(ws + L.off_entries); }
     uint2 *entry_pairs() const { return reinterpret_cast<uint2 *>(ws + L.off_entries); }   // (with a triangle order)
+    uint2 *pairbins() const { return reinterpret_cast<uint2 *>(ws + L.off_pairbins); }
 };
 
 // Swap chain of `depth` (crender_pipeline_*): frame i runs entirely on the pipeline's stream

@@ -438,7 +438,7 @@ struct TileLists {
 CR_DEV bool load_record(const TileLists &L, const float *__restrict__ proj, const Geom &G, uint32_t idx,
                         uint32_t &id, TriXYZ &t, uint32_t &ebx, uint32_t &eby)
 {
-    if (L.offs) {
+    if (L.pairs || L.offs) {
         uint32_t at;                 // position in the arrays
         if (L.pairs) {
             const uint2 e = reinterpret_cast<const uint2 *>(L.entries)[idx];
@@ -1456,7 +1456,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     // 16-pixel tiles with direct bins (at most 65536 triangles): a depth key's low word carries
     // the triangle index in its high half as usual and, in its low half, where the record sits
     // in LDS — batch and slot — so that the resolve takes the winner's edge constants from there
-    const bool slotted = TS == 16 && !L.offs;
+    const bool slotted = TS == 16 && !L.offs && !L.pairs;
     // first batch of the tile's list straight into registers
     uint32_t cur_id = 0, cur_bx = 0, cur_by = 0;
     TriXYZ cur_t{};
@@ -1780,16 +1780,17 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
 #else
     const int dbg = dev_knobs();
 #endif
-    const bool direct = plan->last_frame_direct;
+    const bool direct = plan->last_frame_direct;          // direct bins of 48-byte entries (small scenes)
+    const bool pairbins = plan->last_frame_pairbins;      // fixed-capacity slabs of (position, index) pairs (k_bin_wave)
     const int par = plan->parity;
     TileLists tl;
-    tl.offs = direct ? nullptr : plan->offs();
+    tl.offs = direct || pairbins ? nullptr : plan->offs();
     tl.count = plan->count(par);
     tl.count_next = plan->count(par ^ 1);
-    tl.entries = plan->entries();
+    tl.entries = pairbins ? reinterpret_cast<const uint32_t *>(plan->pairbins()) : plan->entries();
     tl.pairs = !direct && plan->last_frame_pairs;
     tl.bins = plan->direct();
-    tl.capacity = direct ? (uint32_t)L.direct_cap : (uint32_t)L.capacity;
+    tl.capacity = direct ? (uint32_t)L.direct_cap : pairbins ? (uint32_t)L.pair_cap : (uint32_t)L.capacity;
     tl.T = (uint32_t)plan->last_T;
     tl.orig_of = plan->orig_of;
     tl.pos_of = plan->pos_of;
@@ -1817,7 +1818,7 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     // this launch's usage record (crender_plan_poll_bin_usage)
     plan->ticket++;
     const int uslot = (int)(plan->ticket % kUsageRing);
-    plan->usage_direct[uslot] = direct;
+    plan->usage_mode[uslot] = direct ? 1 : pairbins ? 2 : 0;
     tl.hdr = plan->hdr();
     tl.usage = plan->usage_dev + 4 * uslot;
     tl.usage_seq = (uint32_t)plan->ticket;

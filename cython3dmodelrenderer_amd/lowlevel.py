@@ -101,6 +101,10 @@ class Plan:
     def last_frame_direct(self):
         return bool(self._lib.crender_plan_last_frame_direct(self.handle))
 
+    def last_frame_binning(self):
+        """0 = count / scan / fill, 1 = direct bins, 2 = pair bins."""
+        return int(self._lib.crender_plan_last_frame_binning(self.handle))
+
     def bin_usage(self):
         need, cap = C.c_int64(), C.c_int64()
         with torch.cuda.device(self.device):

@@ -54,10 +54,12 @@ enum {
      * the strip exactly once.  Equivalent to crender_clear followed by a flag-less
      * call, without the extra pass over the framebuffer. */
     CRENDER_FUSED_CLEAR = 1u,
-    /* Always bin through the count / scan / fill passes.  Without it, scenes of up to 65536
-     * triangles are binned by appending straight into fixed-capacity per-tile lists (one
-     * launch instead of three); a frame that does not fit reports so through
-     * crender_plan_last_bin_usage, and the plan then uses the general path by itself. */
+    /* Always bin through the count / scan / fill passes.  Without it, scenes are binned in ONE pass
+     * by appending straight into fixed-capacity per-tile lists — of 48-byte entries that carry the
+     * projected triangle for scenes of up to 65536 triangles (the "direct bins"), of 8-byte (position,
+     * index) pairs for larger ones (the "pair bins", three times the mean list per tile) — one launch
+     * instead of three; a frame that does not fit reports so through crender_plan_last_bin_usage /
+     * crender_plan_poll_bin_usage, and the plan then uses the general path by itself. */
     CRENDER_NO_DIRECT_BINS = 2u,
     /* This frame is one of several in flight on the GPU (a swap chain: crender_pipeline_*).  On
      * frames up to 1024 x 1024 a lone frame is rendered for latency: its raster launch starts the
@@ -124,13 +126,17 @@ CRENDER_API void crender_plan_destroy(crender_plan *plan);
 /* Synchronises `stream`, then reports the number of bin-list entries the most recent
  * crender_raster / crender_render_model on this plan needed and the capacity it had.
  * needed > capacity means that frame dropped fragments and must be rendered again:
- *   - if crender_plan_last_frame_direct(plan) is 1 the frame used the direct bins (figures
- *     are then per tile); the plan has switched itself to the general path, just re-render;
+ *   - if crender_plan_last_frame_direct(plan) is 1 the frame used fixed-capacity bins (direct bins or
+ *     pair bins: figures are then per tile); the plan has switched itself to the general path, just
+ *     re-render;
  *   - otherwise recreate the plan with bin_capacity >= needed first. */
 CRENDER_API int crender_plan_last_bin_usage(crender_plan *plan, void *stream,
                                 int64_t *needed, int64_t *capacity);
 
 CRENDER_API int crender_plan_last_frame_direct(crender_plan *plan);
+/* How the most recent frame was binned: 0 = count / scan / fill, 1 = direct bins, 2 = pair bins
+ * (crender_plan_last_frame_direct is 1 for both kinds of fixed-capacity bins). */
+CRENDER_API int crender_plan_last_frame_binning(crender_plan *plan);
 
 /* The same figures WITHOUT a host round trip, per frame (no reference counterpart: the reference's
  * render_model, .pyx:92-104, returns when the buffers are written; a caller of this library that wants

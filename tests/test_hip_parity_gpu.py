@@ -262,7 +262,9 @@ def test_frame_shapes_and_camera_parameters(hip, oracle, H, W, fov, zn, zf, mode
 
 @pytest.mark.parametrize("T", [65535, 65536, 65537])
 def test_direct_bin_triangle_limit(hip, oracle, T):
-    """Scenes of up to 65536 triangles use the direct bins, larger ones the scan path."""
+    """Scenes of up to 65536 triangles use the direct bins (48-byte entries, binning mode 1), larger ones
+    the pair bins (one pass into per-tile slabs of (position, index) pairs, mode 2) — or, when asked
+    (CRENDER_NO_DIRECT_BINS), the count / scan / fill passes (mode 0)."""
     rng = np.random.default_rng(T)
     tri, col, nrm = random_soup(rng, T, 512, size_px=(0.5, 5))
     f = oracle_frame(oracle, tri, col, nrm, 384, 512)
@@ -270,10 +272,14 @@ def test_direct_bin_triangle_limit(hip, oracle, T):
     fb = hip.FrameBuffers(384, 512)
     plan = hip.Plan(384, 512, T)
     hip.render_model(plan, _dev(tri), _dev(col), _dev(nrm), P, fb)
-    assert plan.last_frame_direct() == (T <= 65536)
+    assert plan.last_frame_direct() and plan.last_frame_binning() == (1 if T <= 65536 else 2)
     need, cap = plan.bin_usage()
     assert need <= cap
     compare(tuple(fb.numpy()) + (None,), f, f"T={T}")
+    fb2 = hip.FrameBuffers(384, 512)
+    hip.render_model(plan, _dev(tri), _dev(col), _dev(nrm), P, fb2, direct_bins=False)
+    assert not plan.last_frame_direct() and plan.last_frame_binning() == 0
+    compare(tuple(fb2.numpy()) + (None,), f, f"T={T}, scan path")
 
 
 @pytest.mark.parametrize("mode,tile", [("fused", 16), ("fused", 32), ("fused", 64), ("fused-scan", 32),
@@ -1594,6 +1600,44 @@ def test_overflow_found_late_replays_the_sequence_in_order(oracle):
     assert_bit_equal(filler.get_normals_buffer(), f.normals_buffer, "normal")
     assert_bit_equal(filler.get_winner_tensor().cpu().numpy(), f.winner, "winner")
     assert filler._extra_flags & _capi.NO_DIRECT_BINS, "the first frame was meant to overflow the direct bins"
+
+
+def test_pair_bins_overflow_falls_back_to_the_scan_path(hip, oracle):
+    """Scenes beyond the direct bins (more than 65 536 triangles) are binned in ONE pass into fixed-capacity
+    per-tile slabs of (position, index) pairs (k_bin_wave), sized at three times the mean list.  80 000
+    small triangles crowded into the middle of a 512 x 512 frame outgrow their slabs: the frame reports the
+    overflow like the direct bins do (per-tile figures, crender_plan_last_frame_direct = 1), the plan goes
+    back to count / scan / fill by itself, and the frame rendered again is the oracle's; the filler does
+    all of that behind render_arrays.  The same scene spread over the frame fits and never leaves the
+    pair bins."""
+    from cython3dmodelrenderer_amd import _capi
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    rng = np.random.default_rng(41)
+    H = W = 512
+    for margin, overflows in ((-0.9, True), (0.1, False)):
+        tri, col, nrm = random_soup(rng, 80_000, H, size_px=(2, 7), frac_backface=0.1, margin=margin)
+        f = oracle_frame(oracle, tri, col, nrm, H, W)
+        # C ABI: first frame through the pair bins, the redo (if any) through the scan path
+        P = hip.projection_matrix(45.0, 0.1, 1000.0, H, W)
+        fb = hip.FrameBuffers(H, W)
+        t, c, n = _dev(tri), _dev(col), _dev(nrm)
+        plan = hip.Plan(H, W, len(tri), tile=32)
+        hip.render_model(plan, t, c, n, P, fb, clear=True)
+        need, cap = plan.bin_usage()
+        assert plan.last_frame_binning() == 2 and cap == (3 * len(tri) // 256 + 64 + 63) // 64 * 64
+        assert (need > cap) == overflows, (need, cap)
+        if overflows:
+            hip.render_model(plan, t, c, n, P, fb, clear=True)
+            need2, cap2 = plan.bin_usage()
+            assert not plan.last_frame_direct() and plan.last_frame_binning() == 0 and need2 <= cap2 and cap2 != cap
+        compare(fb.numpy() + (None,), f, f"pair bins, margin {margin}")
+        # the filler, numpy inputs
+        filler = AdvancedPixelBufferFiller(H, W, fov=45, tile=32, track_winner=True)
+        filler.render_arrays(tri, col, nrm)
+        assert_bit_equal(filler.get_z_buffer(), f.z_buffer, f"filler z, margin {margin}")
+        assert_bit_equal(filler.get_color_buffer(), f.color_buffer, "filler colour")
+        assert_bit_equal(filler.get_winner_tensor().cpu().numpy(), f.winner, "filler winner")
+        assert bool(filler._extra_flags & _capi.NO_DIRECT_BINS) == overflows
 
 
 def test_poll_bin_usage_c_abi(hip):
