@@ -43,7 +43,10 @@ constexpr int kThreads = 256;           // 4 wavefronts per workgroup
 // kernel is limited by its 48 KB of LDS, not by registers.  (r01 A/B, same box.)
 constexpr int kWavesPerSimd16 = 7, kWavesPerSimd32 = 6;   // (32-pixel tiles: 28.7 KB of LDS = 5 workgroups per CU)
 constexpr int kItemPixels = 2;      // samples per work item of the per-pixel sweep of 16-pixel tiles
-constexpr int kItemPixels32 = 2;    // the same for the small-record batches of 32-pixel tiles
+#ifndef CRENDER_ITEM32
+#define CRENDER_ITEM32 2
+#endif
+constexpr int kItemPixels32 = CRENDER_ITEM32;    // the same for the small-record batches of 32-pixel tiles
 constexpr uint32_t kPixelPathRecords = 8;   // k_raster<16>: batches this short go pixel-parallel
 constexpr uint32_t kNoTiles = 0xFFFFFFFFu;
 
