@@ -61,7 +61,10 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
     }
     L.pair_cap = 0;
     if (L.direct_cap == 0 && max_T > 0) {
-        int64_t pc = (3 * max_T / L.g.ntiles + 64 + 63) / 64 * 64;
+#ifndef CRENDER_PAIR_MULT
+#define CRENDER_PAIR_MULT 3
+#endif
+        int64_t pc = (CRENDER_PAIR_MULT * max_T / L.g.ntiles + 64 + 63) / 64 * 64;
         if (pc > 8192) pc = 8192;
         if (pc * (int64_t)sizeof(uint2) * L.g.ntiles <= kPairBinBytes) L.pair_cap = pc;
     }
