@@ -4,6 +4,8 @@
 // bin_pass (binning.hip) and raster_pass (raster.hip).
 #include "plan.h"
 
+#include <mutex>
+
 namespace crender_detail {
 
 thread_local std::string g_last_error;
@@ -129,6 +131,73 @@ int tile_frame(crender_plan *plan, bool project, const float *d_tri, const float
     return CRENDER_OK;
 }
 
+// Pinned host memory for the plans' usage records: one allocation of kUsageSlots slots, made at the first
+// plan and kept for the life of the process (portable: every device's kernels may write into it); a plan
+// takes a slot and gives it back.  Beyond kUsageSlots plans alive at once, a plan gets an allocation of
+// its own.
+void usage_slot_give(uint32_t *host, int slot);
+constexpr int kUsageSlots = 1024;
+constexpr size_t kUsageSlotWords = 4 * (kUsageRing + 2);
+struct UsagePool {
+    std::mutex m;
+    uint32_t *host = nullptr;
+    std::vector<int> free_slots;
+};
+UsagePool &usage_pool()
+{
+    static UsagePool pool;
+    return pool;
+}
+
+hipError_t usage_slot_take(uint32_t **host, uint32_t **dev, int *slot)
+{
+    UsagePool &P = usage_pool();
+    void *h = nullptr;
+    *slot = -1;
+    {
+        std::lock_guard<std::mutex> lock(P.m);
+        if (!P.host) {
+            void *block = nullptr;
+            const hipError_t e = hipHostMalloc(&block, sizeof(uint32_t) * kUsageSlotWords * kUsageSlots,
+                                               hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable);
+            if (e != hipSuccess) return e;
+            P.host = static_cast<uint32_t *>(block);
+            for (int i = kUsageSlots - 1; i >= 0; --i) P.free_slots.push_back(i);
+        }
+        if (!P.free_slots.empty()) {
+            *slot = P.free_slots.back();
+            P.free_slots.pop_back();
+            h = P.host + (size_t)*slot * kUsageSlotWords;
+        }
+    }
+    if (!h) {
+        const hipError_t e = hipHostMalloc(&h, sizeof(uint32_t) * kUsageSlotWords, hipHostMallocMapped | hipHostMallocCoherent);
+        if (e != hipSuccess) return e;
+    }
+    std::memset(h, 0, sizeof(uint32_t) * kUsageSlotWords);
+    void *d = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) {
+        usage_slot_give(static_cast<uint32_t *>(h), *slot);
+        return e;
+    }
+    *host = static_cast<uint32_t *>(h);
+    *dev = static_cast<uint32_t *>(d);
+    return hipSuccess;
+}
+
+void usage_slot_give(uint32_t *host, int slot)
+{
+    if (!host) return;
+    if (slot < 0) {
+        (void)hipHostFree(host);
+        return;
+    }
+    UsagePool &P = usage_pool();
+    std::lock_guard<std::mutex> lock(P.m);
+    P.free_slots.push_back(slot);
+}
+
 // What the header words of a frame mean (crender_plan_last_bin_usage, crender_plan_poll_bin_usage).
 void usage_figures(crender_plan *plan, int mode, uint32_t h0, uint32_t h1, uint32_t h4, int64_t *needed,
                    int64_t *capacity)
@@ -207,24 +276,15 @@ int crender_plan_create(crender_plan **out, int H, int W, int y0, int y1, int64_
     p->ws = static_cast<unsigned char *>(d_workspace);
     // header + per-tile counters start at zero; the frame kernels keep them zero
     hipError_t e = hipMemsetAsync(p->ws, 0, L.off_offs, static_cast<hipStream_t>(stream));
-    // the per-frame usage records: pinned, coherent host memory the raster launches write into
-    void *host = nullptr;
-    if (e == hipSuccess)
-        e = hipHostMalloc(&host, sizeof(uint32_t) * 4 * (kUsageRing + 2), hipHostMallocMapped | hipHostMallocCoherent);
+    // the per-frame usage records: pinned, coherent host memory the raster launches write into — a
+    // slot of the process-wide pool (hipHostMalloc / hipHostFree per plan cost milliseconds, and the
+    // free synchronises the device: a filler collected in the middle of another one's frames showed as
+    // 0.3 ms per call)
+    if (e == hipSuccess) e = usage_slot_take(&p->usage, &p->usage_dev, &p->usage_slot);
     if (e != hipSuccess) {
         delete p;
         return fail_hip(e, "crender_plan_create (workspace memset / pinned usage records)");
     }
-    std::memset(host, 0, sizeof(uint32_t) * 4 * (kUsageRing + 2));
-    p->usage = static_cast<uint32_t *>(host);
-    void *dev = nullptr;
-    e = hipHostGetDevicePointer(&dev, host, 0);
-    if (e != hipSuccess) {
-        (void)hipHostFree(host);
-        delete p;
-        return fail_hip(e, "hipHostGetDevicePointer(usage records)");
-    }
-    p->usage_dev = static_cast<uint32_t *>(dev);
     *out = p;
     return CRENDER_OK;
 }
@@ -233,7 +293,7 @@ void crender_plan_destroy(crender_plan *plan)
 {
     if (!plan) return;
     for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
-    if (plan->usage) (void)hipHostFree(plan->usage);
+    usage_slot_give(plan->usage, plan->usage_slot);
     delete plan;
 }
 
