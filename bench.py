@@ -236,16 +236,26 @@ def cpu_baseline(workload, synth_T, max_triangles, api=False, budget_s=16.0, pas
 
 
 def _timed(call, sync, budget):
+    """ms per call: warm-up, then the calls in ten chunks, each closed by `sync`; the MEDIAN chunk.  (One
+    total over all calls carried one-off stalls of the process — 60-130 ms once, somewhere in a loop of
+    200 calls, seen only in this script's fourth Renderer loop and not when every call is timed by itself,
+    scripts/fused_probe.py — as +0.3-0.6 ms "per call".)"""
     call(); call(); sync()                  # warm-up: plans, pinned buffers, staging
     t0 = time.perf_counter()
     call(); sync()
     one = time.perf_counter() - t0
     n = int(max(3, min(200, budget / max(one, 1e-5))))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        call()
-    sync()
-    return (time.perf_counter() - t0) / n * 1e3
+    chunks = min(10, n)
+    per = max(1, n // chunks)
+    times = []
+    for _ in range(chunks):
+        t0 = time.perf_counter()
+        for _ in range(per):
+            call()
+        sync()
+        times.append((time.perf_counter() - t0) / per * 1e3)
+    times.sort()
+    return times[len(times) // 2]
 
 
 class _Model:
@@ -275,7 +285,8 @@ def api_calls(tri, col, nrm, H, W, fov, device, budget_s=3.0):
     def dsync():
         torch.cuda.synchronize(device)
 
-    out = {"unit": "ms per call", "model_arrays": "host numpy, uploaded by every call (as the reference copies them)"}
+    out = {"unit": "ms per call (median of ten chunks of calls, each chunk closed by a device synchronisation)",
+           "model_arrays": "host numpy, uploaded by every call (as the reference copies them)"}
     f = AdvancedPixelBufferFiller(H, W, fov=fov, device=device)
     out["render_model_ms"] = timed(lambda: f.render_model(m), dsync)
     # the same call when the caller waits for the GPU after each one (what a caller that reads the
