@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("k_raster", "k_frame", "k_setup", "k_count_wave", "k_scan", "k_fill", "k_project", "k_clear", "k_keys_init",
+    for k in ("k_raster", "k_frame", "k_setup", "k_bin_wave", "k_count_wave", "k_scan", "k_fill", "k_project", "k_clear", "k_keys_init",
               "k_cover_atomic", "k_resolve_global", "k_guro"):
         if k in name:
             return k
