@@ -549,6 +549,7 @@ CR_DEV void build_order(const uint32_t *__restrict__ count, int ntx, int nty,
         const uint32_t ncov = tot[0] + tot[1] + tot[2];
         hint_next[1] = ncov + tot[3];                       // tiles with a workgroup of their own
         hint_next[2] = (tot[4] + group - 1) / group;        // workgroups that clear `group` tiles each
+        hint_next[3] = tot[0];                              // of them, the first so many hold the long lists (class 0)
         hint_next[0] = ncov ? 1u : 0u;     // an empty frame says nothing about the next one
     }
 }
@@ -773,7 +774,8 @@ CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad
     const int tid = threadIdx.x;
     CR_TILE_DBG(c);
     // ---- which tile, and which part of it --------------------------------------------------
-    // grid = [order builder, if ordered][3 * hmax helpers][ntiles main workgroups, one tile each]
+    // grid = [order builder, if ordered][3 * hmax helpers][ntiles main workgroups, one tile each]; an ordered
+    // launch reads it as [builder][covered tiles, longest lists first][helpers][groups of empty tiles]
     if (L.order_next) {
         if (b == 0) {
             build_order(L.count, G.ntx, G.nty, L.order_next, L.grouped_next, L.hint_next, reinterpret_cast<uint32_t *>(qraw), group_tiles(TS));
@@ -781,16 +783,33 @@ CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad
         }
         b -= 1;
     }
-    const bool helper = b < L.nhelp;
+    // An ORDERED launch with helpers starts the own workgroups of the tiles with LONG lists first (class 0 of
+    // the order: 32 records or more — the launch ends when the slowest of them does), then the helpers that
+    // take the other parts of the heavy tiles, then the rest of the order.  With the helpers leading the
+    // grid (the unordered layout) a heavy tile's own workgroup started 2-3 us into the launch, behind up to
+    // 1 536 helper slots (in-kernel stamps, profiles/r05: lone k_frame<32,true> 14.3 -> 12.9 us stamped);
+    // with ALL covered tiles ahead of the helpers the parts of the heaviest tiles started behind the light ones.
+    // (On 16-pixel plans the helpers stay in front: there they are few, and the one more dependent load in
+    // front of their slot word cost the parts of the heaviest tiles more than the earlier start of the own
+    // workgroups gained: k_raster<16,true> 14.2 -> 15.4 us.)
+    int lead = 0;                                               // own workgroups ahead of the helpers
+#ifndef CRENDER_HELPERS_FIRST
+    if constexpr (TS == 32) {
+        const bool ordered_now = L.nhelp > 0 && L.order && L.hint[0] && !*L.hint_bad;
+        lead = ordered_now ? (int)L.hint[3] : 0;
+    }
+#endif
+    const bool helper = b >= lead && b < lead + L.nhelp;
     quad = -1;                   // -1 = the whole tile, 0..3 = one part of a heavy tile (half or quadrant)
     if (helper) {
         // part 1..3 of the heavy tile registered in this workgroup's slot, if any
+        b -= lead;                                       // (its slot)
         const uint32_t v = L.heavy_slots[b];
         if (v == 0) return false;                        // (same word for every thread: uniform)
         tile = (int)v - 1;
         quad = 1 + b % 3;
     } else {
-        const int m = b - L.nhelp;
+        const int m = b < lead ? b : b - L.nhelp;
         if (m == 0 && tid == 0) {
             if (L.heavy_ctr_next) *L.heavy_ctr_next = 0;
             *L.hint_bad_next = 0;
