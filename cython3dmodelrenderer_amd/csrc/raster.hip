@@ -416,6 +416,7 @@ struct TileLists {
     const uint32_t *orig_of, *pos_of;
     // heavy tiles (see register_heavy): null / 0 when the launch has no helper workgroups
     uint32_t *heavy_flag, *heavy_slots, *heavy_ctr_next;
+    const uint32_t *heavy_ctr;  // how many tiles THIS frame's binning pass registered (it ran in an earlier launch)
     int nhelp;                  // 3 * hmax helper workgroups
     // dispatch order (see build_order): null when the launch is not ordered
     int addr32;                  // framebuffer and attribute byte offsets fit 32 bits (see elem())
@@ -792,14 +793,28 @@ CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad
     // (On 16-pixel plans the helpers stay in front: there they are few, and the one more dependent load in
     // front of their slot word cost the parts of the heaviest tiles more than the earlier start of the own
     // workgroups gained: k_raster<16,true> 14.2 -> 15.4 us.)
+    // Of the 3 * hmax helper slots only the first 3 * (tiles registered) hold work — T-Rex 1024^2: 936 of
+    // 1 536 — and an empty slot's workgroup still lives the 1.5 us its dependent loads take, in front of the
+    // own workgroups of the short lists, which then started 3-4 us into the launch, into the flood of the empty
+    // tiles' clears, and ended it (stamps, profiles/r05).  The ordered launch counts the slots in use (the
+    // binning pass's registration counter) and sends the unused ones to the END of the grid, where they leave
+    // without a look at their slot word: it is zero, nobody registered there.
     int lead = 0;                                               // own workgroups ahead of the helpers
+    int used = L.nhelp;                                         // helper slots in front of the other own workgroups
 #ifndef CRENDER_HELPERS_FIRST
     if constexpr (TS == 32) {
         const bool ordered_now = L.nhelp > 0 && L.order && L.hint[0] && !*L.hint_bad;
-        lead = ordered_now ? (int)L.hint[3] : 0;
+        if (ordered_now) {
+            lead = (int)L.hint[3];
+#ifndef CRENDER_ALL_HELPER_SLOTS
+            const uint32_t reg = *L.heavy_ctr, hmax = (uint32_t)L.nhelp / 3u;
+            used = 3 * (int)(reg < hmax ? reg : hmax);
+#endif
+        }
     }
 #endif
-    const bool helper = b >= lead && b < lead + L.nhelp;
+    if (b >= G.ntiles + used) return false;                     // (an unused helper slot)
+    const bool helper = b >= lead && b < lead + used;
     quad = -1;                   // -1 = the whole tile, 0..3 = one part of a heavy tile (half or quadrant)
     if (helper) {
         // part 1..3 of the heavy tile registered in this workgroup's slot, if any
@@ -809,7 +824,7 @@ CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad
         tile = (int)v - 1;
         quad = 1 + b % 3;
     } else {
-        const int m = b < lead ? b : b - L.nhelp;
+        const int m = b < lead ? b : b - used;
         if (m == 0 && tid == 0) {
             if (L.heavy_ctr_next) *L.heavy_ctr_next = 0;
             *L.hint_bad_next = 0;
@@ -1115,9 +1130,20 @@ CR_DEV void owner_path32(const Tile<32> &c, int nrec)
     // one LDS read
     float *pre = reinterpret_cast<float *>(key);
     if (tid < nrec) {
-        const TriSetup st = make_setup(TriXYZ{q.x0[tid], q.y0[tid], q.z0[tid], q.x1[tid], q.y1[tid], q.z1[tid],
-                                               q.x2[tid], q.y2[tid], q.z2[tid]}, true);
+        // (the constants of a record with a box are in q.pre since the queue was written; one without a box
+        // gets no band bit below and is never looked at)
         const uint32_t bwh = packed_wh(q.box[tid]), bxy = packed_xy(q.box[tid], X0, Y0);
+        TriSetup st;
+        st.x0 = q.x0[tid]; st.y0 = q.y0[tid]; st.z0 = q.z0[tid];
+        st.x1 = q.x1[tid]; st.y1 = q.y1[tid]; st.z1 = q.z1[tid];
+        st.x2 = q.x2[tid]; st.y2 = q.y2[tid]; st.z2 = q.z2[tid];
+        st.l01 = st.x1 - st.x2; st.l02 = st.y1 - st.y2;
+        st.l11 = st.x2 - st.x0; st.l12 = st.y2 - st.y0;
+        st.l21 = st.x0 - st.x1; st.l22 = st.y0 - st.y1;
+        st.l03 = q.pre.l03[tid]; st.l13 = q.pre.l13[tid]; st.l23 = q.pre.l23[tid];
+        st.r1 = q.pre.r1[tid]; st.r2 = q.pre.r2[tid]; st.r3 = q.pre.r3[tid];
+        st.fast = st.r1 != 0.0f;
+        st.rej1 = rej_sign(st.l03); st.rej2 = rej_sign(st.l13); st.rej3 = rej_sign(st.l23);
         uint32_t flags = st.fast ? kOwnFast : 0u;
         flags |= (uint32_t)(st.rej1 > 0.0f ? 1 : st.rej1 < 0.0f ? 2 : 0) << 5;
         flags |= (uint32_t)(st.rej2 > 0.0f ? 1 : st.rej2 < 0.0f ? 2 : 0) << 7;
@@ -1445,6 +1471,14 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
         // the other parity's counter of this tile: zero for the next frame
         if (tid == 0) L.count_next[tile] = 0;
     }
+    // 32-pixel tiles of a small frame rendered alone (the launches with helper workgroups), fused clear: the key
+    // plane's start value is a constant — written while the list length is still on its way, one barrier off
+    // a workgroup's chain (lone k_frame<32,true> 15.9 -> 15.6 us).  Should the tile turn out to be the pixel
+    // owners', they take the plane for their per-record words behind the queue's barrier.  Not on the large
+    // frames: there most tiles are empty or the owners' and never need a key plane (bunny 4096^2 +3 % with it).
+    // (Composite frames start from the depth buffer: see the batch loop.)
+    const bool keys_early = TS == 32 && CLEAR && L.nhelp > 0;
+    if (keys_early) init_keys<TS, CLEAR>(c);
     int rw = TS;                 // width of this workgroup's rectangle in the key plane's terms
     if (quad >= 0) {
         constexpr int HS = TS / 2;
@@ -1565,6 +1599,17 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             if (lane == 63) q.wave_blocks[wave] = incl;
             if constexpr (either) {
                 if (lane == 63) q.wave_px[wave] = incl_px;
+                // every record's thread works out, ONCE, what an item of its record would otherwise work out
+                // again (9 items of two pixels per record on the 10 M small triangles: 40 of an item's 175
+                // vector instructions) — here, with the queue, not behind a barrier of its own once the batch
+                // has picked its sweep: the pixel owners take their constants from here too, and a batch
+                // that goes by culled blocks overwrites them (q.big shares the memory)
+                if (box_wh != 0) {
+                    const TriSetup mine = make_setup(cur_t, true);
+                    q.pre.l03[tid] = mine.l03; q.pre.l13[tid] = mine.l13; q.pre.l23[tid] = mine.l23;
+                    q.pre.r1[tid] = mine.fast ? mine.r1 : 0.0f; q.pre.r2[tid] = mine.r2; q.pre.r3[tid] = mine.r3;
+                }
+                q.pre.px_scan[tid] = incl_px - my_px;
             }
         }
         __syncthreads();  // queue complete
@@ -1583,18 +1628,9 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             const uint32_t blk_excl = incl - my_blocks;
             bool small_by_pixel = false;    // 32-pixel tiles: small records go per pixel too
             if constexpr (either) small_by_pixel = total < 16 * nrec && !(dbg & 8192);
-            if constexpr (either) {
-                if (small_by_pixel) {
-                    // every record's thread works out, ONCE, what an item of its record would otherwise
-                    // work out again (9 items of two pixels per record on the 10 M small triangles:
-                    // 40 of an item's 175 vector instructions)
-                    const TriSetup mine = make_setup(cur_t, true);
-                    q.pre.l03[tid] = mine.l03; q.pre.l13[tid] = mine.l13; q.pre.l23[tid] = mine.l23;
-                    q.pre.r1[tid] = mine.fast ? mine.r1 : 0.0f; q.pre.r2[tid] = mine.r2; q.pre.r3[tid] = mine.r3;
-                    q.pre.px_scan[tid] = incl_px - my_px;
-                    __syncthreads();
-                }
-            }
+#ifdef CRENDER_STAMPS
+            if (base == beg) CR_STAMP(13);
+#endif
             // next batch: issue its loads now, they complete under the sweeps
             const uint32_t nxt = base + kBatch + tid;
             cur_ok = tid < kBatch && nxt < end;
@@ -1605,10 +1641,13 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                     owner_path32<CLEAR>(c, nrec);
                     return;
                 }
-                if (base == beg) {
+                if (base == beg && !keys_early) {
                     init_keys<TS, CLEAR>(c);
                     __syncthreads();
                 }
+#ifdef CRENDER_STAMPS
+                if (base == beg) CR_STAMP(14);         // key plane initialised (composite frames)
+#endif
             }
             if constexpr (per_pixel) {
                 sweep_items<TS>(c, scan16, wo, total, nrec);
@@ -1622,17 +1661,26 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                     // development knob: the run-wise walk is faster on every workload once the key plane is
                     // swizzled, T-Rex 1024^2 pipelined +12 %, 10 M small triangles' raster launch -4 %)
                     const int items = (int)wop[kThreads / 64];
+#ifdef CRENDER_STAMPS
+                    if (g_stamps && base == beg && tid == 0) g_stamps[stamp_base + 12] = (unsigned long long)items;
+#endif
 #ifdef CRENDER_RUNS_MAX_AVG
                     if ((dbg & (1 << 30)) || items > CRENDER_RUNS_MAX_AVG * nrec) sweep_items<TS>(c, q.pre.px_scan, wop, items, nrec); else
 #else
                     if (dbg & (1 << 30)) sweep_items<TS>(c, q.pre.px_scan, wop, items, nrec); else
 #endif
                     sweep_runs32(c, wop, items);
+#ifdef CRENDER_STAMPS
+                    if (base == beg) CR_STAMP(15);     // thread 0's run of the first batch walked
+#endif
                 }
             } else if constexpr (TS == 64) {
                 if ((total < 16 * nrec && !(dbg & 8192)) || (dbg & 128)) walk64_small(c, wo, total);
                 else walk64_dense(c, wo, total);
             } else {
+#ifdef CRENDER_STAMPS
+                if (g_stamps && base == beg && tid == 0) g_stamps[stamp_base + 12] = (1ull << 32) | (unsigned long long)total;
+#endif
                 sweep_blocks_culled<TS>(c, wo, total, blk_excl);
             }
         }
@@ -1817,6 +1865,7 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     tl.heavy_flag = split ? plan->hflag() : nullptr;
     tl.heavy_slots = split ? plan->hslots() : nullptr;
     tl.heavy_ctr_next = plan->hdr() + 2 + (par ^ 1);
+    tl.heavy_ctr = plan->hdr() + 2 + par;
     tl.nhelp = split ? 3 * L.hmax : 0;
     // ordered launches: read the order the previous launch left, leave one for the next
     const bool ordered = direct && L.ordered && plan->frame_lone && !(dbg & 1024);

@@ -80,11 +80,36 @@ for lo, hi in ((1, 8), (8, 16), (16, 32), (32, 64), (64, 128), (128, 100000)):
     if m.any():
         print(f"   list [{lo},{hi}): {int(m.sum()):4d} quadrant workgroups, sweeps p50 {np.percentile((sw - qd)[m], 50):5.2f} max {(sw - qd)[m].max():5.2f}, "
               f"resolve p50 {np.percentile(((ce - cs) - sw)[m], 50):5.2f}, life p50 {np.percentile((ce - cs)[m], 50):5.2f} max {(ce - cs)[m].max():5.2f}")
+# word 12: the FIRST batch's work as the sweep counts it — items of two pixels (run-wise sweep) or, with bit 32, 16-pixel blocks
+it = c[:, 12] & 0xFFFFFFFF
+blk = (c[:, 12] >> 32) != 0
+own = (c[:, 12] == 0)
+print(f"first batch's sweep: {int((~blk & ~own).sum())} workgroups run-wise (two-pixel items), {int(blk.sum())} by culled blocks, {int(own.sum())} pixel owners / pixel path")
+for lo, hi in ((1, 64), (64, 128), (128, 256), (256, 512), (512, 1024), (1024, 100000)):
+    m = (~blk & ~own) & (it >= lo) & (it < hi)
+    if m.any():
+        print(f"   first-batch items [{lo},{hi}): {int(m.sum()):4d} workgroups, sweeps p50 {np.percentile((sw - qd)[m], 50):5.2f} max {(sw - qd)[m].max():5.2f} us")
+# words 13 / 14 / 15: inside the first batch's sweep phase — per-record constants in LDS, key plane initialised,
+# thread 0's own run walked (the workgroup's other wavefronts may still be walking: "swept" is behind the barrier)
+rw_ = (~blk & ~own) & (c[:, 13] != 0) & (c[:, 14] != 0) & (c[:, 15] != 0)
+if rw_.any():
+    p13, p14, p15 = ((c[rw_, j] - c[rw_, 0]) / 100.0 for j in (13, 14, 15))
+    q6, s2 = qd[rw_], sw[rw_]
+    one = rw_ & (c[:, 4] <= 256)
+    print("inside the sweep phase of run-wise workgroups, durations p50 / p90 (us): constants of the records -> LDS %.2f / %.2f, "
+          "key plane %.2f / %.2f, thread 0's run %.2f / %.2f, rest (other wavefronts, later batches, barrier) %.2f / %.2f" % (
+              *np.percentile(p13 - q6, [50, 90]), *np.percentile(p14 - p13, [50, 90]), *np.percentile(p15 - p14, [50, 90]),
+              *np.percentile(s2 - p15, [50, 90])))
+    chunkn = np.ceil(it[rw_] / 256.0)
+    for k in (1, 2, 3, 4, 5, 6):
+        m = chunkn == k
+        if m.any():
+            print(f"   {k} item(s) per thread: {int(m.sum()):4d} workgroups, thread 0's run p50 {np.percentile((p15 - p14)[m], 50):5.2f} p90 {np.percentile((p15 - p14)[m], 90):5.2f} us")
 last = np.argsort(-ce)[:10]
-print("last workgroups to end (tile, quadrant, list, start, known, landed, queued, swept, end):")
+print("last workgroups to end (tile, quadrant, list, first batch's items or blocks, start, known, landed, queued, swept, end):")
 for i in last:
-    print("   tile %4d q%d list %4d: start %.2f +%.2f +%.2f +%.2f +%.2f end %.2f" % (
-        c[i, 8], c[i, 9] - 1, c[i, 4], cs[i], rd[i], ld[i], qd[i], sw[i], ce[i]))
+    print("   tile %4d q%d list %4d %s %5d: start %.2f +%.2f +%.2f +%.2f +%.2f end %.2f" % (
+        c[i, 8], c[i, 9] - 1, c[i, 4], "blocks" if blk[i] else "items", it[i], cs[i], rd[i], ld[i], qd[i], sw[i], ce[i]))
 print("resident workgroups over time (all / covered), every 1 us:")
 hi = en.max()
 for t in np.arange(0.0, hi, 1.0):
