@@ -1638,6 +1638,15 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             if constexpr (TS == 32) {
                 // the whole list is this one batch of large records: the pixels' owners take it from here
                 if (base == beg && end - beg <= (uint32_t)kBatch && !small_by_pixel && !(dbg & 32768)) {
+                    // (a heavy tile's hand-off words go back to zero HERE: this path returns, and every wavefront
+                    // read them before the queue's barrier.  Without it a frame of large triangles on a split
+                    // 32-pixel plan left its flags up, and the next frame cleared only the upper half of the
+                    // tiles it no longer covered: test_dispatch_order_hint_never_changes_pixels[True-32].
+                    // A `break` to the common exit instead costs 76 spilled registers.)
+                    if (quad >= 0 && tid == 0) {
+                        if (!helper) L.heavy_flag[tile] = 0;
+                        else L.heavy_slots[b] = 0;
+                    }
                     owner_path32<CLEAR>(c, nrec);
                     return;
                 }

@@ -986,13 +986,17 @@ def test_synthetic_small_triangles_at_4096(hip, oracle):
         assert_bit_equal(a, b, f"idempotence: {what}")
 
 
+@pytest.mark.parametrize("tile", [16, 32])
 @pytest.mark.parametrize("clear", [True, False])
-def test_dispatch_order_hint_never_changes_pixels(hip, oracle, clear):
-    """On 16-pixel tiles each raster launch leaves a dispatch order for the next launch on the same
+def test_dispatch_order_hint_never_changes_pixels(hip, oracle, clear, tile):
+    """On small frames each raster launch leaves a dispatch order for the next launch on the same
     plan (covered tiles first, empty tiles cleared in groups without a look at their lists).  The
     order is a hint about speed only: frames of the same model, of another model (stale order), of
     the model moved by a few pixels and by half a frame, and of no triangles at all, rendered one
-    after another on ONE plan, must each equal the oracle bit for bit."""
+    after another on ONE plan, must each equal the oracle bit for bit.  On 32-pixel tiles every covered
+    tile is split among four workgroups through a table of helper slots, and an ordered launch counts the
+    slots in use and sends the rest to the end of its grid: the soup covers more tiles than there are
+    slots, the cube and T-Rex fewer, the empty frame none — in every order of succession."""
     H = W = 512
     tri, col, nrm = scene("trex_inputs.npz")
     ctri, ccol, cnrm = scene("cube_inputs.npz")
@@ -1011,9 +1015,14 @@ def test_dispatch_order_hint_never_changes_pixels(hip, oracle, clear):
               (e, e, e), (tri, col, nrm), (moved(0.4, -0.3), col, nrm), (stri, scol, snrm),
               (stri, scol, snrm), (tri, col, nrm)]
     P = hip.projection_matrix(45.0, 0.1, 1000.0, H, W)
-    plan = hip.Plan(H, W, max(len(tri), len(stri)), tile=16)
+    plan = hip.Plan(H, W, max(len(tri), len(stri)), tile=tile)
     fb = hip.FrameBuffers(H, W)
     ref = oracle.OracleFiller(H, W, fov=45.0)
+    if tile == 32:
+        # (a soup that touches more tiles than the plan has helper triples — 256 tiles, 128 triples)
+        s2 = random_soup(np.random.default_rng(6), 3000, H, size_px=(2, 12))
+        frames = frames + [s2, (tri, col, nrm), s2, s2, (e, e, e), s2, (ctri, ccol, cnrm)]
+        plan = hip.Plan(H, W, max(len(tri), len(stri), len(s2[0])), tile=tile)
     for k, (t, c, n) in enumerate(frames):
         if clear:
             ref.clear()
@@ -1026,7 +1035,7 @@ def test_dispatch_order_hint_never_changes_pixels(hip, oracle, clear):
             hip.render_model(plan, z, z, z, P, fb, clear=clear)
         need, cap = plan.bin_usage()
         assert need <= cap and plan.last_frame_direct()
-        compare(tuple(fb.numpy()) + (None,), ref, f"frame {k} on one plan (clear={clear})")
+        compare(tuple(fb.numpy()) + (None,), ref, f"frame {k} on one plan (clear={clear}, tile={tile})")
 
 
 def test_synthetic_10m_matches_golden(hip, golden):
