@@ -1053,12 +1053,15 @@ def test_synthetic_10m_matches_golden(hip, golden):
         assert_bit_equal(a, b, f"synth10m: tile path vs atomic path, {what}")
 
 
-@pytest.mark.parametrize("res,tile", [(512, 0), (1024, 0), (1536, 0)])
-def test_pipeline_lookahead_bins_the_next_frame_in_the_raster_launch(oracle, res, tile):
+@pytest.mark.parametrize("res,tile,depth", [(512, 0, 0), (1024, 0, 0), (1536, 0, 0), (512, 0, 1), (1024, 0, 1)])
+def test_pipeline_lookahead_bins_the_next_frame_in_the_raster_launch(oracle, res, tile, depth):
     """Swap chain with look-ahead (crender_pipeline_set_lookahead): every launch rasterizes one frame
     and bins the slot's next one into a second plan.  Frames must be the oracle's whatever the
     history: bursts of any length, a join in between, another model (the plans were binned ahead for
-    the old one), back again, and look-ahead off for comparison — 16- and 32-pixel tiles."""
+    the old one), back again, and look-ahead off for comparison — 16- and 32-pixel tiles.  depth 1: the
+    chain renders every frame ALONE — covered 32-pixel tiles in four quadrants through the helper slots,
+    dispatch in the previous frame's order — and the cube's tiles (a few large triangles each: the pixel
+    owners') give way to T-Rex's (small records) and back."""
     from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
     tri, col, nrm = scene("trex_inputs.npz")
     ctri, ccol, cnrm = scene("cube_inputs.npz")
@@ -1074,7 +1077,7 @@ def test_pipeline_lookahead_bins_the_next_frame_in_the_raster_launch(oracle, res
 
     for look in (True, False):
         filler = AdvancedPixelBufferFiller(res, res, fov=45, tile=tile, pipeline=True, track_winner=True,
-                                           lookahead=look)
+                                           lookahead=look, **({"pipeline_depth": depth} if depth else {}))
         filler.render_arrays(tri, col, nrm, clear=True)
         assert filler._pipe is None or filler._pipe.lookahead == look
         for burst in (1, 2, 3, 4, 5, 9):
@@ -1096,6 +1099,12 @@ def test_pipeline_lookahead_bins_the_next_frame_in_the_raster_launch(oracle, res
         for _ in range(7):
             filler.render_frame()
         check(filler, ft, f"look-ahead {look}, T-Rex again")
+        for who, (a, b, c_), f in (("cube", (ctri, ccol, cnrm), fc), ("T-Rex", (tri, col, nrm), ft),
+                                   ("cube", (ctri, ccol, cnrm), fc), ("T-Rex", (tri, col, nrm), ft)):
+            filler.render_arrays(a, b, c_, clear=True)               # straight from one model to the other
+            for _ in range(3):
+                filler.render_frame()
+            check(filler, f, f"look-ahead {look}, depth {depth}: {who} right after the other model")
         # every framebuffer set of the chain holds the frame
         for k, (z, c, n, w) in enumerate(filler._pipe.sets):
             assert_bit_equal(z.cpu().numpy(), ft.z_buffer, f"set {k}: z")
