@@ -591,14 +591,19 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
     const int par = (int)(plan->frame_no++ & 1u);
     plan->parity = par;
     plan->frame_lone = !(flags & CRENDER_OVERLAPPED_FRAMES) || (dbg & 16384);
-    if (plan->awaiting[par]) {
-        // this parity was binned into and no raster pass has run since (two crender_prepare calls
-        // in a row): start over from the state crender_plan_create leaves
+    if (plan->awaiting[par] || plan->unrastered[par ^ 1]) {
+        // this parity was binned into and not zeroed since, or the other one was binned into and never
+        // rasterized (the swap chain binned ahead for inputs that then changed; crender_prepare twice in a
+        // row): start over from the state crender_plan_create leaves.  (The second case was missed until
+        // round 5: the discarded frame's tiles kept their split flags, and the next frame on the plan
+        // cleared only half of those it did not cover — test_lone_chain_through_changing_scenes.)
         CR_HIP(hipMemsetAsync(plan->ws + L.off_count, 0, L.off_order - L.off_count, s));
         CR_HIP(hipMemsetAsync(plan->hdr() + 2, 0, 5 * sizeof(uint32_t), s));   // heavy counters, hint_bad
         plan->awaiting[0] = plan->awaiting[1] = false;
+        plan->unrastered[0] = plan->unrastered[1] = false;
     }
     plan->awaiting[par] = true;
+    plan->unrastered[par] = true;
     uint32_t *count = plan->count(par);
 
     // contiguous chunk of triangles per block, a multiple of the block size

@@ -61,10 +61,14 @@ struct crender_plan {
     // The per-tile counters exist twice.  Frame f bins into parity f & 1 and its raster pass
     // zeroes the OTHER parity for frame f + 1, so no raster workgroup ever writes a counter that
     // another workgroup of the same launch reads (the four workgroups of a heavy tile all read
-    // its count).  awaiting[p]: parity p was binned into and not zeroed since.
+    // its count).  awaiting[p]: parity p was binned into and not zeroed since.  unrastered[p]: parity p was
+    // binned into and its raster pass has not been launched — a binning pass that finds the OTHER parity so
+    // (bins filled ahead for inputs that then changed, crender_prepare twice) starts over as well: the flag
+    // and helper-slot words of the split tiles and the order hint exist once, not per parity.
     unsigned frame_no = 0;
     int parity = 0;               // of the last bin pass
     bool awaiting[2] = {false, false};
+    bool unrastered[2] = {false, false};
     uint32_t *count(int par) const { return reinterpret_cast<uint32_t *>(ws + L.off_count) + (size_t)par * L.count_stride; }
     uint32_t *hflag() const { return reinterpret_cast<uint32_t *>(ws + L.off_hflag); }
     uint32_t *hslots() const { return reinterpret_cast<uint32_t *>(ws + L.off_hslots); }

@@ -1912,6 +1912,7 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
                 hipLaunchKernelGGL((k_frame<TS, false>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, fa);
             CR_LAUNCH_CHECK("k_frame");
             plan->awaiting[par ^ 1] = false;
+            plan->unrastered[par] = false;
             return CRENDER_OK;
         }
     }
@@ -1923,6 +1924,7 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
                            d_z, d_color, d_normal, d_winner, G, dbg);
     CR_LAUNCH_CHECK("k_raster");
     plan->awaiting[par ^ 1] = false;     // zeroed by this launch
+    plan->unrastered[par] = false;
     return CRENDER_OK;
 }
 

@@ -833,6 +833,65 @@ def test_pipeline_c_abi_lookahead(oracle, hip, H, W, flags_extra):
         lib.crender_pipeline_destroy(pipe)
 
 
+@pytest.mark.parametrize("res,tile,clear", [(512, 32, True), (512, 32, False), (1024, 32, True), (512, 16, True)])
+def test_lone_chain_through_changing_scenes(oracle, hip, res, tile, clear):
+    """The swap chain of depth 1 with look-ahead — the chain bench.py's `roofline` view dispatches: one frame
+    at a time, k_frame, every covered 32-pixel tile in four quadrants through flag and helper-slot words,
+    dispatch in the previous frame's order, the slot's NEXT frame binned ahead into its other plan — fed a
+    DIFFERENT scene every few frames: T-Rex (small records), the cube (a few large triangles: the pixel
+    owners' tiles), a soup that touches more tiles than the plans have helper triples, a frame of no
+    triangles.  Whatever the previous launches left behind — an order for other tiles, hand-off words,
+    bins filled ahead for another model — every frame is the oracle's, bit for bit."""
+    import ctypes as C
+    import torch
+    from cython3dmodelrenderer_amd import _capi
+    L, lib = hip, _capi.load()
+    H = W = res
+    trex = scene("trex_inputs.npz")
+    cube = scene("cube_inputs.npz")
+    big = random_soup(np.random.default_rng(11), 4000, H, size_px=(2, 14))
+    few = random_soup(np.random.default_rng(12), 60, H, size_px=(20, 90))
+    none = tuple(np.zeros((0, 3, 3), np.float32) for _ in range(3))
+    scenes_ = {"trex": trex, "cube": cube, "big": big, "few": few, "none": none}
+    dev = {k: [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in v] for k, v in scenes_.items()}
+    maxT = max(len(v[0]) for v in scenes_.values())
+    P = L.projection_matrix(45, 0.1, 1000.0, H, W)
+    plans = [L.Plan(H, W, maxT, tile=tile) for _ in range(2)]
+    fb = L.FrameBuffers(H, W, winner=True)
+    pipe = C.c_void_p()
+    first = (C.c_void_p * 1)(plans[0].handle.value)
+    second = (C.c_void_p * 1)(plans[1].handle.value)
+    _capi.check(lib.crender_pipeline_create(C.byref(pipe), first, 1), "create")
+    stream = torch.cuda.current_stream().cuda_stream
+    flags = _capi.FUSED_CLEAR if clear else 0
+    ref = oracle.OracleFiller(H, W, fov=45.0)
+    order = ["trex", "trex", "trex", "cube", "cube", "trex", "big", "big", "cube", "none", "trex", "few", "few",
+             "big", "none", "none", "cube", "trex", "few", "cube", "big", "trex", "trex"]
+    try:
+        _capi.check(lib.crender_pipeline_set_lookahead(pipe, second, 1), "set_lookahead")
+        for k, name in enumerate(order):
+            t, c, n = dev[name]
+            if clear:
+                ref.clear()
+            ref.render_arrays(*scenes_[name])
+            _capi.check(lib.crender_pipeline_frame(
+                pipe, t.data_ptr(), c.data_ptr(), n.data_ptr(), t.shape[0], _capi.f32_16(P),
+                fb.z.data_ptr(), fb.color.data_ptr(), fb.normals.data_ptr(), fb.winner.data_ptr(), flags, stream),
+                "frame")
+            if k % 3 != 1:            # (two frames in a row without a join now and then)
+                _capi.check(lib.crender_pipeline_join(pipe, stream), "join")
+                z, cc, nn, w = fb.numpy()
+                what = f"frame {k} ({name} after {order[k - 1] if k else '-'}), {res}^2, tile {tile}, clear={clear}"
+                assert_bit_equal(z, ref.z_buffer, what + ": z")
+                assert_bit_equal(cc, ref.color_buffer, what + ": colour")
+                assert_bit_equal(nn, ref.normals_buffer, what + ": normal")
+                if clear:
+                    assert_bit_equal(w, ref.winner, what + ": winner")
+    finally:
+        torch.cuda.synchronize()
+        lib.crender_pipeline_destroy(pipe)
+
+
 @pytest.mark.parametrize("direction", [[0.3, -0.2, 1], [0, 0, 1]])
 def test_renderer_with_illumination(oracle, direction):
     """Renderer.render in its four forms against the oracle's render + the oracle's own C
