@@ -392,6 +392,76 @@ def test_fuzz_random_configurations(hip, oracle, seed):
     assert_bit_equal(got[3][touched], f.winner[touched], what + ": winner")
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_many_frames_on_the_same_plans(hip, oracle, seed):
+    """Seeded fuzz over what a plan CARRIES from frame to frame — counter parities, the split tiles' flag and
+    helper-slot words, the dispatch-order hint, sticky overflow switches, bins filled and never drawn: one set
+    of plans (the whole frame, or two or three row strips), twenty-odd frames of scenes drawn at random from
+    a pool (T-Rex, the cube, soups of small / large / very many triangles, no triangles), each through a
+    randomly chosen entry point — render_model, project + raster, prepare + draw, prepare TWICE (the first
+    binning discarded) + draw — with or without the direct bins, with or without fused clear; after every
+    frame the buffers are the oracle's, which was fed the same sequence.  Even seeds: plans for at most
+    20 000 triangles (direct bins: small frames are split and ordered); odd seeds: plans for 90 000 (pair
+    bins, scan path on request)."""
+    import torch
+    rng = np.random.default_rng(7000 + seed)
+    big_family = seed % 2 == 1
+    H = int(rng.choice([256, 384, 512, 700])); W = int(rng.choice([256, 512, 640]))
+    tile = int(rng.choice([0, 16, 32, 32]))
+    fov = 45.0
+    pool = {"trex": scene("trex_inputs.npz"), "cube": scene("cube_inputs.npz"),
+            "small": random_soup(rng, 3000, max(H, W), size_px=(1, 10)),
+            "large": random_soup(rng, 80, max(H, W), size_px=(20, 120)),
+            "none": tuple(np.zeros((0, 3, 3), np.float32) for _ in range(3))}
+    if big_family:
+        pool["many"] = random_soup(rng, 90_000, max(H, W), size_px=(0.5, 4))
+    maxT = max(len(v[0]) for v in pool.values())
+    dev = {k: [_dev(a) for a in v] for k, v in pool.items()}
+    cuts = sorted(set(int(v) for v in rng.integers(1, H, int(rng.integers(0, 3)))) | {0, H})
+    strips = [(a, b) for a, b in zip(cuts, cuts[1:]) if b > a]
+    plans = [hip.Plan(H, W, maxT, y0=a, y1=b, tile=tile) for a, b in strips]
+    fb = hip.FrameBuffers(H, W)
+    ref = oracle.OracleFiller(H, W, fov=fov)
+    P = hip.projection_matrix(fov, 0.1, 1000.0, H, W)
+    names = list(pool)
+    history = []
+    for k in range(22):
+        name = names[int(rng.integers(0, len(names)))]
+        how = str(rng.choice(["fused", "fused", "split", "prepare+draw", "prepare twice"]))
+        direct = bool(rng.integers(0, 4) > 0)
+        clear = bool(rng.integers(0, 2))
+        other = names[int(rng.integers(0, len(names)))]
+        history.append((name, how, direct, clear))
+        t, c, n = dev[name]
+        T = t.shape[0]
+        if clear:
+            ref.clear()
+        for (a, b) in strips:
+            ref.render_arrays(*pool[name], y0=a, y1=b)
+        proj = hip.project(t, P, W, H) if how == "split" and T else None
+        for plan in plans:
+            for attempt in range(2):
+                if how == "fused" or T == 0:
+                    hip.render_model(plan, t, c, n, P, fb, clear=clear, direct_bins=direct)
+                elif how == "split":
+                    hip.raster(plan, proj, c, n, fb, clear=clear, direct_bins=direct)
+                else:
+                    if how == "prepare twice" and dev[other][0].shape[0]:
+                        hip.prepare(plan, dev[other][0], dev[other][2], P, direct_bins=direct)   # never drawn
+                    hip.prepare(plan, t, n, P, direct_bins=direct)
+                    hip.draw(plan, c, n, T, fb, clear=clear, direct_bins=direct)
+                need, cap = plan.bin_usage()
+                if need <= cap:
+                    break
+                assert attempt == 0, (need, cap, history)      # a plan switches to roomier bins once
+        z, cb, nb, win = fb.numpy()
+        what = f"stateful fuzz {seed}: {H}x{W} tile {tile} strips {strips}, frame {k} of {history}"
+        assert_bit_equal(z, ref.z_buffer, what + ": z")
+        assert_bit_equal(cb, ref.color_buffer, what + ": colour")
+        assert_bit_equal(nb, ref.normals_buffer, what + ": normal")
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("clear", [False, True])
 def test_no_triangles(hip, oracle, clear):
     empty = np.zeros((0, 3, 3), np.float32)
