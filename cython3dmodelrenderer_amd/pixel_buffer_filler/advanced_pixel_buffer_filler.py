@@ -756,7 +756,16 @@ class AdvancedPixelBufferFiller:
         here: the snapshot is retaken, the swap chain drops what it binned ahead.  Bare tensors under
         ``presort=True`` keep the snapshot of the last ``render_model`` / ``render_arrays`` call, and
         bare tensors rewritten in place under a swap chain need ``render_model`` again (the protocol of
-        ``crender_pipeline_join``)."""
+        ``crender_pipeline_join``).
+
+        numpy arrays handed out by the getters are NOT refreshed by this call (no PCIe traffic in the frame
+        loop): they show the frame after the next getter call, and what is written into them before that
+        is lost."""
+        # The frame starts from cleared buffers: whatever the caller wrote into arrays the getters handed out
+        # is void, and those arrays are stale from here until the next getter call refreshes them — they
+        # must not be carried back over this frame by a later compositing render (they were, until round 5:
+        # getter, render_frame, render_model lost the frame; test_fuzz_a_filler_through_a_random_session).
+        self._host_exposed = False
         model = self._model_ref() if self._model_ref is not None else None
         if model is not None and model.generation != self._model_generation:
             # The resident model has rewritten its arrays since (DeviceModel.shift / rotate / scale count
@@ -797,6 +806,7 @@ class AdvancedPixelBufferFiller:
         of north_star's "projected vertices broadcast" layout (distributed.StripRenderer).  `proj`
         is a [T, 3, 3] float32 device tensor in the resident model's triangle order."""
         self._join_pipe()
+        self._host_exposed = False         # (a cleared frame: see render_frame)
         tri, col, nrm = self._inputs
         if self._order is not None:
             raise ValueError("render_projected_frame needs the resident model in the caller's order (presort=False)")

@@ -392,7 +392,7 @@ def test_fuzz_random_configurations(hip, oracle, seed):
     assert_bit_equal(got[3][touched], f.winner[touched], what + ": winner")
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(40))
 def test_fuzz_many_frames_on_the_same_plans(hip, oracle, seed):
     """Seeded fuzz over what a plan CARRIES from frame to frame — counter parities, the split tiles' flag and
     helper-slot words, the dispatch-order hint, sticky overflow switches, bins filled and never drawn: one set
@@ -406,8 +406,8 @@ def test_fuzz_many_frames_on_the_same_plans(hip, oracle, seed):
     import torch
     rng = np.random.default_rng(7000 + seed)
     big_family = seed % 2 == 1
-    H = int(rng.choice([256, 384, 512, 700])); W = int(rng.choice([256, 512, 640]))
-    tile = int(rng.choice([0, 16, 32, 32]))
+    H = int(rng.choice([256, 384, 512, 700, 1024])); W = int(rng.choice([256, 512, 640, 1024]))
+    tile = int(rng.choice([0, 16, 32, 32, 64]))
     fov = 45.0
     pool = {"trex": scene("trex_inputs.npz"), "cube": scene("cube_inputs.npz"),
             "small": random_soup(rng, 3000, max(H, W), size_px=(1, 10)),
@@ -459,6 +459,109 @@ def test_fuzz_many_frames_on_the_same_plans(hip, oracle, seed):
         assert_bit_equal(z, ref.z_buffer, what + ": z")
         assert_bit_equal(cb, ref.color_buffer, what + ": colour")
         assert_bit_equal(nb, ref.normals_buffer, what + ": normal")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_a_filler_through_a_random_session(oracle, seed):
+    """Seeded fuzz of the drop-in CLASS: one AdvancedPixelBufferFiller, forty-odd calls drawn at random —
+    render_model on numpy models (composite, as the reference; or clear=True), render_arrays on device
+    tensors, bursts of render_frame (with and without the swap chain, depth 1 or the default), clear(),
+    getters, in-place edits of the arrays the getters handed out followed by a composite render (the edit
+    must be under the new fragments, guro_illumination.py:27 does exactly this), in-place edits of a model's
+    vertex array between two render_model calls (.pyx:94-96 re-reads them) — against an oracle filler that is
+    told the same story.  Every getter call along the way is compared bit for bit."""
+    import torch
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    rng = np.random.default_rng(9000 + seed)
+    H = int(rng.choice([200, 256, 512, 640])); W = int(rng.choice([256, 320, 512]))
+    kw = {}
+    if seed % 3 == 1:
+        kw = {"pipeline": True}
+    elif seed % 3 == 2:
+        kw = {"pipeline": True, "pipeline_depth": 1}
+    if rng.integers(0, 2):
+        kw["tile"] = int(rng.choice([16, 32]))
+
+    class M:
+        def __init__(self, t, c, n):
+            self._vertices_by_triangles, self._colors_by_triangles, self._normals_by_triangles = t, c, n
+
+    pool = {"trex": scene("trex_inputs.npz"), "cube": scene("cube_inputs.npz"),
+            "small": random_soup(rng, 2500, max(H, W), size_px=(1, 9)),
+            "large": random_soup(rng, 60, max(H, W), size_px=(20, 110)),
+            "none": tuple(np.zeros((0, 3, 3), np.float32) for _ in range(3))}
+    models = {k: M(*(a.copy() for a in v)) for k, v in pool.items()}
+    names = list(pool)
+    f = AdvancedPixelBufferFiller(H, W, fov=45, **kw)
+    ref = oracle.OracleFiller(H, W, fov=45.0)
+    views = {}
+    story = []
+    resident = None                     # what render_frame renders: the arrays of the last render call
+
+    def check(what):
+        for name, get, want in (("z", f.get_z_buffer, ref.z_buffer), ("colour", f.get_color_buffer, ref.color_buffer),
+                                ("normal", f.get_normals_buffer, ref.normals_buffer)):
+            views[name] = get()
+            assert_bit_equal(views[name], want, f"filler session {seed} ({H}x{W}, {kw}): {what}: {name}; story {story}")
+
+    for step in range(44):
+        op = str(rng.choice(["model", "model", "model clear", "arrays", "frames", "clear", "check", "edit view",
+                             "edit model"]))
+        name = names[int(rng.integers(0, len(names)))]
+        story.append((op, name))
+        if op == "model" or op == "model clear":
+            clear = op == "model clear"
+            if clear:
+                ref.clear()
+            m = models[name]
+            ref.render_arrays(m._vertices_by_triangles, m._colors_by_triangles, m._normals_by_triangles)
+            f.render_model(m, clear=clear)
+            resident = (m._vertices_by_triangles.copy(), m._colors_by_triangles, m._normals_by_triangles)
+        elif op == "arrays":
+            clear = bool(rng.integers(0, 2))
+            if clear:
+                ref.clear()
+            ref.render_arrays(*pool[name])
+            f.render_arrays(*(_dev(a) for a in pool[name]), clear=clear)
+            resident = pool[name]
+        elif op == "frames":
+            if resident is None:
+                continue
+            for _ in range(int(rng.integers(1, 6))):
+                f.render_frame()
+            ref.clear()
+            ref.render_arrays(*resident)
+        elif op == "clear":
+            f.clear()
+            ref.clear()
+        elif op == "check":
+            check(f"step {step}")
+        elif op == "edit view":
+            # the caller writes into an array a getter handed out; the next render composites on top of it
+            check(f"step {step}, before the edit")
+            y0 = int(rng.integers(0, H - 8)); x0 = int(rng.integers(0, W - 8))
+            hh, ww = int(rng.integers(1, 8)), int(rng.integers(1, 8))
+            zval = np.float32(rng.choice([0.3, 0.9, 2.0, 1e6]))
+            for v, r in ((views["z"], ref.z_buffer),):
+                v[y0:y0 + hh, x0:x0 + ww] = zval
+                r[y0:y0 + hh, x0:x0 + ww] = zval
+            cval = np.float32(rng.uniform(0, 255))
+            views["colour"][y0:y0 + hh, x0:x0 + ww] = cval
+            ref.color_buffer[y0:y0 + hh, x0:x0 + ww] = cval
+            m = models[name]
+            ref.render_arrays(m._vertices_by_triangles, m._colors_by_triangles, m._normals_by_triangles)
+            f.render_model(m)
+            resident = (m._vertices_by_triangles.copy(), m._colors_by_triangles, m._normals_by_triangles)
+            check(f"step {step}, render on top of the edited arrays")
+        elif op == "edit model":
+            m = models[name]
+            if len(m._vertices_by_triangles):
+                m._vertices_by_triangles[..., 0] += np.float32(rng.uniform(-0.02, 0.02))     # in place
+            ref.render_arrays(m._vertices_by_triangles, m._colors_by_triangles, m._normals_by_triangles)
+            f.render_model(m)
+            resident = (m._vertices_by_triangles.copy(), m._colors_by_triangles, m._normals_by_triangles)
+    check("the end")
     torch.cuda.synchronize()
 
 
