@@ -1108,6 +1108,65 @@ def test_renderer_with_illumination(oracle, direction):
     assert_bit_equal(img_f, f.color_buffer, "Renderer.render (illumination fused into the raster kernel)")
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_renderers_sharing_one_filler(oracle, seed):
+    """Seeded sessions of ``Renderer.render`` (cy/renderer.py:47-49: render_model, draw_illumination on the
+    WHOLE colour buffer, return it) through all four forms of this package's Renderer — numpy illumination on
+    the host views, the default (shading on the device, the numpy view returned), on_device=True (the tensor)
+    and "fused" (a frame from cleared buffers, shaded as it is stored) — taking turns on ONE filler, with bursts
+    of render_frame and a clear() in between: renders composite on buffers that earlier renders have already
+    shaded (the reference's behaviour: reset_buffers is a no-op), so every form must leave exactly the bits
+    the next one starts from.  The oracle: its filler + its own C restatement of guro_illumination.py:20-27."""
+    import torch
+    from cython3dmodelrenderer_amd import Renderer
+    from cython3dmodelrenderer_amd.illumination import GuroIllumination
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    rng = np.random.default_rng(11000 + seed)
+    H = int(rng.choice([192, 256, 320])); W = int(rng.choice([256, 384]))
+    direction = [[0.3, -0.2, 1], [0, 0, 1], [-0.5, 0.4, 0.7]][seed % 3]
+    light = GuroIllumination(direction)
+    kw = {"pipeline": True} if seed % 2 else {}
+    filler = AdvancedPixelBufferFiller(H, W, fov=45, **kw)
+    forms = {m: Renderer(filler, light, None, H, W, on_device=m) for m in (False, None, True, "fused")}
+    ref = oracle.OracleFiller(H, W, fov=45.0)
+    pool = {"trex": scene("trex_inputs.npz"), "cube": scene("cube_inputs.npz"),
+            "small": random_soup(rng, 1500, max(H, W), size_px=(1, 9)),
+            "large": random_soup(rng, 40, max(H, W), size_px=(20, 110))}
+    names = list(pool)
+    story = []
+    for step in range(18):
+        name = names[int(rng.integers(0, len(names)))]
+        form = [False, None, None, True, "fused", "frames", "clear"][int(rng.integers(0, 7))]
+        story.append((form, name))
+        if form == "clear":
+            filler.clear(); ref.clear()
+            continue
+        if form == "frames":
+            # (the swap chain's frames shade too once an illumination has been fused into the filler)
+            if filler._inputs is None:
+                continue
+            last = story_last_inputs
+            for _ in range(int(rng.integers(1, 4))):
+                filler.render_frame()
+            ref.clear()
+            ref.render_arrays(*last)
+            if filler._fused_light is not None:
+                oracle.guro(ref.color_buffer, ref.normals_buffer, direction)
+            got = filler.get_color_buffer()
+        else:
+            if form == "fused":
+                ref.clear()
+            ref.render_arrays(*pool[name])
+            oracle.guro(ref.color_buffer, ref.normals_buffer, direction)
+            img = forms[form].render(_M(*pool[name]))
+            got = img.cpu().numpy() if isinstance(img, torch.Tensor) else img
+            story_last_inputs = pool[name]
+        what = f"renderer session {seed} ({H}x{W}, {kw}, light {direction}), step {step} of {story}"
+        assert_bit_equal(got, ref.color_buffer, what + ": colour")
+        assert_bit_equal(filler.get_z_buffer(), ref.z_buffer, what + ": z")
+        assert_bit_equal(filler.get_normals_buffer(), ref.normals_buffer, what + ": normal")
+
+
 @pytest.mark.parametrize("res,tile", [(256, 0), (300, 32), (192, 64), (1024, 0)])
 def test_fused_guro_equals_the_separate_pass(oracle, hip, res, tile):
     """CRENDER_FUSED_GURO: the raster kernel shades each pixel as it stores it.  Bit for bit the
