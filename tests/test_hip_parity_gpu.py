@@ -2119,6 +2119,71 @@ def test_device_model_trex_from_the_mesh_to_the_golden_pixels(golden):
     assert sha(filler.get_winner_tensor().cpu().numpy()) == g["winner"]
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_a_device_model_moved_between_renders(oracle, seed):
+    """Seeded sessions with a model that lives in HBM (DeviceModel): shifts and scales — HIP kernels that
+    rewrite the by-triangle arrays in place and are bit-exact with the host Model's numpy — in between
+    render_model calls (composite or cleared), bursts of render_frame (no swap chain, the default chain, the
+    chain of depth 1; plain or with the tile-coherent snapshot ``presort=True``) that must notice the moved
+    model by its generation count, and getters; the oracle renders the HOST Model's arrays, transformed by the
+    same calls.  (join() before a transform while frames are in flight: the class's documented protocol.)"""
+    import torch
+    from cython3dmodelrenderer_amd.data_structures import DeviceModel, Model
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    from cython3dmodelrenderer_amd.scenes import GOLDEN_DIR, fit_model
+    with np.load(os.path.join(GOLDEN_DIR, "trex_mesh.npz")) as z:
+        vertices, faces = z["vertices"], z["faces"]
+    rng = np.random.default_rng(13000 + seed)
+    H = int(rng.choice([256, 384, 512])); W = int(rng.choice([256, 512]))
+    kw = [{}, {"pipeline": True}, {"pipeline": True, "pipeline_depth": 1}][seed % 3]
+    if seed % 4 == 3:
+        kw = dict(kw, presort=True)
+    hm = Model(vertices, faces)
+    hm.set_uniform_color((40.0, 180.0, 250.0))
+    dm = DeviceModel(Model(vertices, faces))
+    dm.set_uniform_color((40.0, 180.0, 250.0))
+    fit_model(hm); fit_model(dm)
+    filler = AdvancedPixelBufferFiller(H, W, fov=45, **kw)
+    ref = oracle.OracleFiller(H, W, fov=45.0)
+    story = []
+
+    def host_arrays():
+        return hm._vertices_by_triangles, hm._colors_by_triangles, hm._normals_by_triangles
+
+    rendered = False
+    for step in range(26):
+        op = str(rng.choice(["shift", "shift", "scale", "render", "render", "render clear", "frames", "frames", "check"]))
+        story.append(op)
+        if op in ("shift", "scale"):
+            filler.join()
+            if op == "shift":
+                v = [float(rng.uniform(-0.08, 0.08)), float(rng.uniform(-0.08, 0.08)), float(rng.uniform(-0.1, 0.2))]
+                hm.shift(v); dm.shift(v)
+            else:
+                c = float(rng.uniform(0.85, 1.15))
+                hm.scale(c); dm.scale(c)
+        elif op in ("render", "render clear"):
+            if op == "render clear":
+                ref.clear()
+            ref.render_arrays(*host_arrays())
+            filler.render_model(dm, clear=op == "render clear")
+            rendered = True
+        elif op == "frames":
+            if not rendered:
+                continue
+            for _ in range(int(rng.integers(1, 5))):
+                filler.render_frame()
+            ref.clear()
+            ref.render_arrays(*host_arrays())
+        if op in ("check", "frames", "render", "render clear") and rendered:
+            what = f"device-model session {seed} ({H}x{W}, {kw}), step {step} of {story}"
+            assert_bit_equal(dm._vertices_by_triangles.cpu().numpy(), hm._vertices_by_triangles, what + ": the arrays")
+            assert_bit_equal(filler.get_z_buffer(), ref.z_buffer, what + ": z")
+            assert_bit_equal(filler.get_color_buffer(), ref.color_buffer, what + ": colour")
+            assert_bit_equal(filler.get_normals_buffer(), ref.normals_buffer, what + ": normal")
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("on_device_model", [False, True])
 def test_renderer_normalize_model_fit(oracle, on_device_model):
     """Renderer.render(model, normalize_model=True) — the reference's fit of the model into the image
