@@ -482,6 +482,12 @@ def test_fuzz_a_filler_through_a_random_session(oracle, seed):
         kw = {"pipeline": True, "pipeline_depth": 1}
     if rng.integers(0, 2):
         kw["tile"] = int(rng.choice([16, 32]))
+    if seed % 4 == 0:
+        kw["track_winner"] = True          # (the winner plane must tell the same story)
+    strip = (0, H)
+    if seed % 5 == 4:
+        a = int(rng.integers(0, H // 2)); strip = (a, int(rng.integers(a + 1, H + 1)))
+        kw["row_strip"] = strip            # (a filler that owns some rows of the frame only)
 
     class M:
         def __init__(self, t, c, n):
@@ -497,13 +503,24 @@ def test_fuzz_a_filler_through_a_random_session(oracle, seed):
     ref = oracle.OracleFiller(H, W, fov=45.0)
     views = {}
     story = []
+
+    def ref_clear():                    # (a strip filler clears, and renders, its own rows only)
+        a, b = strip
+        ref.z_buffer[a:b] = np.float32(1e6); ref.color_buffer[a:b] = 0; ref.normals_buffer[a:b] = 0
+        ref.winner[a:b] = -1
     resident = None                     # what render_frame renders: the arrays of the last render call
 
     def check(what):
         for name, get, want in (("z", f.get_z_buffer, ref.z_buffer), ("colour", f.get_color_buffer, ref.color_buffer),
                                 ("normal", f.get_normals_buffer, ref.normals_buffer)):
             views[name] = get()
-            assert_bit_equal(views[name], want, f"filler session {seed} ({H}x{W}, {kw}): {what}: {name}; story {story}")
+            # (a strip filler answers for its own rows; the others belong to whoever fills them — an exchange)
+            assert_bit_equal(views[name][strip[0]:strip[1]], want[strip[0]:strip[1]],
+                             f"filler session {seed} ({H}x{W}, {kw}): {what}: {name}; story {story}")
+        if kw.get("track_winner"):
+            f.synchronize()
+            assert_bit_equal(f.get_winner_tensor().cpu().numpy()[strip[0]:strip[1]], ref.winner[strip[0]:strip[1]],
+                             f"filler session {seed} ({H}x{W}, {kw}): {what}: winner; story {story}")
 
     for step in range(44):
         op = str(rng.choice(["model", "model", "model clear", "arrays", "frames", "clear", "check", "edit view",
@@ -513,16 +530,16 @@ def test_fuzz_a_filler_through_a_random_session(oracle, seed):
         if op == "model" or op == "model clear":
             clear = op == "model clear"
             if clear:
-                ref.clear()
+                ref_clear()
             m = models[name]
-            ref.render_arrays(m._vertices_by_triangles, m._colors_by_triangles, m._normals_by_triangles)
+            ref.render_arrays(m._vertices_by_triangles, m._colors_by_triangles, m._normals_by_triangles, y0=strip[0], y1=strip[1])
             f.render_model(m, clear=clear)
             resident = (m._vertices_by_triangles.copy(), m._colors_by_triangles, m._normals_by_triangles)
         elif op == "arrays":
             clear = bool(rng.integers(0, 2))
             if clear:
-                ref.clear()
-            ref.render_arrays(*pool[name])
+                ref_clear()
+            ref.render_arrays(*pool[name], y0=strip[0], y1=strip[1])
             f.render_arrays(*(_dev(a) for a in pool[name]), clear=clear)
             resident = pool[name]
         elif op == "frames":
@@ -530,18 +547,19 @@ def test_fuzz_a_filler_through_a_random_session(oracle, seed):
                 continue
             for _ in range(int(rng.integers(1, 6))):
                 f.render_frame()
-            ref.clear()
-            ref.render_arrays(*resident)
+            ref_clear()
+            ref.render_arrays(*resident, y0=strip[0], y1=strip[1])
         elif op == "clear":
             f.clear()
-            ref.clear()
+            ref_clear()
         elif op == "check":
             check(f"step {step}")
         elif op == "edit view":
             # the caller writes into an array a getter handed out; the next render composites on top of it
             check(f"step {step}, before the edit")
-            y0 = int(rng.integers(0, H - 8)); x0 = int(rng.integers(0, W - 8))
+            y0 = int(rng.integers(strip[0], max(strip[0] + 1, strip[1] - 8))); x0 = int(rng.integers(0, W - 8))
             hh, ww = int(rng.integers(1, 8)), int(rng.integers(1, 8))
+            hh = min(hh, strip[1] - y0)
             zval = np.float32(rng.choice([0.3, 0.9, 2.0, 1e6]))
             for v, r in ((views["z"], ref.z_buffer),):
                 v[y0:y0 + hh, x0:x0 + ww] = zval
@@ -550,7 +568,7 @@ def test_fuzz_a_filler_through_a_random_session(oracle, seed):
             views["colour"][y0:y0 + hh, x0:x0 + ww] = cval
             ref.color_buffer[y0:y0 + hh, x0:x0 + ww] = cval
             m = models[name]
-            ref.render_arrays(m._vertices_by_triangles, m._colors_by_triangles, m._normals_by_triangles)
+            ref.render_arrays(m._vertices_by_triangles, m._colors_by_triangles, m._normals_by_triangles, y0=strip[0], y1=strip[1])
             f.render_model(m)
             resident = (m._vertices_by_triangles.copy(), m._colors_by_triangles, m._normals_by_triangles)
             check(f"step {step}, render on top of the edited arrays")
@@ -558,7 +576,7 @@ def test_fuzz_a_filler_through_a_random_session(oracle, seed):
             m = models[name]
             if len(m._vertices_by_triangles):
                 m._vertices_by_triangles[..., 0] += np.float32(rng.uniform(-0.02, 0.02))     # in place
-            ref.render_arrays(m._vertices_by_triangles, m._colors_by_triangles, m._normals_by_triangles)
+            ref.render_arrays(m._vertices_by_triangles, m._colors_by_triangles, m._normals_by_triangles, y0=strip[0], y1=strip[1])
             f.render_model(m)
             resident = (m._vertices_by_triangles.copy(), m._colors_by_triangles, m._normals_by_triangles)
     check("the end")
