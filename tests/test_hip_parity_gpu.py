@@ -1024,15 +1024,18 @@ def test_pipeline_c_abi_lookahead(oracle, hip, H, W, flags_extra):
         lib.crender_pipeline_destroy(pipe)
 
 
-@pytest.mark.parametrize("res,tile,clear", [(512, 32, True), (512, 32, False), (1024, 32, True), (512, 16, True)])
-def test_lone_chain_through_changing_scenes(oracle, hip, res, tile, clear):
-    """The swap chain of depth 1 with look-ahead — the chain bench.py's `roofline` view dispatches: one frame
-    at a time, k_frame, every covered 32-pixel tile in four quadrants through flag and helper-slot words,
-    dispatch in the previous frame's order, the slot's NEXT frame binned ahead into its other plan — fed a
-    DIFFERENT scene every few frames: T-Rex (small records), the cube (a few large triangles: the pixel
-    owners' tiles), a soup that touches more tiles than the plans have helper triples, a frame of no
-    triangles.  Whatever the previous launches left behind — an order for other tiles, hand-off words,
-    bins filled ahead for another model — every frame is the oracle's, bit for bit."""
+@pytest.mark.parametrize("res,tile,clear,depth,overlapped", [
+    (512, 32, True, 1, 0), (512, 32, False, 1, 0), (1024, 32, True, 1, 0), (512, 16, True, 1, 0),
+    (512, 32, True, 2, 0), (512, 32, True, 3, 4), (640, 0, False, 3, 4), (512, 32, False, 2, 0), (384, 16, True, 4, 4)])
+def test_lone_chain_through_changing_scenes(oracle, hip, res, tile, clear, depth, overlapped):
+    """The swap chain with look-ahead fed a DIFFERENT scene every few frames.  depth 1 is the chain bench.py's
+    `roofline` view dispatches: one frame at a time, k_frame, every covered 32-pixel tile in four quadrants
+    through flag and helper-slot words, dispatch in the previous frame's order, the slot's NEXT frame binned
+    ahead into its other plan.  Deeper chains rotate framebuffer sets and plans; with CRENDER_OVERLAPPED_FRAMES
+    (4) the frames are not split.  Scenes: T-Rex (small records), the cube (a few large triangles: the pixel
+    owners' tiles), a soup that touches more tiles than the plans have helper triples, a few large triangles,
+    no triangles.  Whatever the previous launches left behind — an order for other tiles, hand-off words,
+    bins filled ahead for another model — every framebuffer set is the oracle's, bit for bit."""
     import ctypes as C
     import torch
     from cython3dmodelrenderer_amd import _capi
@@ -1047,21 +1050,23 @@ def test_lone_chain_through_changing_scenes(oracle, hip, res, tile, clear):
     dev = {k: [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in v] for k, v in scenes_.items()}
     maxT = max(len(v[0]) for v in scenes_.values())
     P = L.projection_matrix(45, 0.1, 1000.0, H, W)
-    plans = [L.Plan(H, W, maxT, tile=tile) for _ in range(2)]
-    fb = L.FrameBuffers(H, W, winner=True)
+    plans = [L.Plan(H, W, maxT, tile=tile) for _ in range(2 * depth)]
+    fbs = [L.FrameBuffers(H, W, winner=True) for _ in range(depth)]
     pipe = C.c_void_p()
-    first = (C.c_void_p * 1)(plans[0].handle.value)
-    second = (C.c_void_p * 1)(plans[1].handle.value)
-    _capi.check(lib.crender_pipeline_create(C.byref(pipe), first, 1), "create")
+    first = (C.c_void_p * depth)(*[p.handle.value for p in plans[:depth]])
+    second = (C.c_void_p * depth)(*[p.handle.value for p in plans[depth:]])
+    _capi.check(lib.crender_pipeline_create(C.byref(pipe), first, depth), "create")
     stream = torch.cuda.current_stream().cuda_stream
-    flags = _capi.FUSED_CLEAR if clear else 0
-    ref = oracle.OracleFiller(H, W, fov=45.0)
+    flags = (_capi.FUSED_CLEAR if clear else 0) | overlapped
+    refs = [oracle.OracleFiller(H, W, fov=45.0) for _ in range(depth)]
     order = ["trex", "trex", "trex", "cube", "cube", "trex", "big", "big", "cube", "none", "trex", "few", "few",
-             "big", "none", "none", "cube", "trex", "few", "cube", "big", "trex", "trex"]
+             "big", "none", "none", "cube", "trex", "few", "cube", "big", "trex", "trex", "cube", "few", "trex"]
     try:
-        _capi.check(lib.crender_pipeline_set_lookahead(pipe, second, 1), "set_lookahead")
+        _capi.check(lib.crender_pipeline_set_lookahead(pipe, second, depth), "set_lookahead")
         for k, name in enumerate(order):
             t, c, n = dev[name]
+            slot = k % depth
+            ref, fb = refs[slot], fbs[slot]
             if clear:
                 ref.clear()
             ref.render_arrays(*scenes_[name])
@@ -1069,15 +1074,17 @@ def test_lone_chain_through_changing_scenes(oracle, hip, res, tile, clear):
                 pipe, t.data_ptr(), c.data_ptr(), n.data_ptr(), t.shape[0], _capi.f32_16(P),
                 fb.z.data_ptr(), fb.color.data_ptr(), fb.normals.data_ptr(), fb.winner.data_ptr(), flags, stream),
                 "frame")
-            if k % 3 != 1:            # (two frames in a row without a join now and then)
+            if k % 3 != 1:            # (frames in a row without a join now and then)
                 _capi.check(lib.crender_pipeline_join(pipe, stream), "join")
-                z, cc, nn, w = fb.numpy()
-                what = f"frame {k} ({name} after {order[k - 1] if k else '-'}), {res}^2, tile {tile}, clear={clear}"
-                assert_bit_equal(z, ref.z_buffer, what + ": z")
-                assert_bit_equal(cc, ref.color_buffer, what + ": colour")
-                assert_bit_equal(nn, ref.normals_buffer, what + ": normal")
-                if clear:
-                    assert_bit_equal(w, ref.winner, what + ": winner")
+                for s_, (r_, b_) in enumerate(zip(refs, fbs)):
+                    z, cc, nn, w = b_.numpy()
+                    what = (f"frame {k} ({name} after {order[k - 1] if k else '-'}), set {s_}, {res}^2, tile {tile}, "
+                            f"clear={clear}, depth {depth}, flags {flags}")
+                    assert_bit_equal(z, r_.z_buffer, what + ": z")
+                    assert_bit_equal(cc, r_.color_buffer, what + ": colour")
+                    assert_bit_equal(nn, r_.normals_buffer, what + ": normal")
+                    if clear:
+                        assert_bit_equal(w, r_.winner, what + ": winner")
     finally:
         torch.cuda.synchronize()
         lib.crender_pipeline_destroy(pipe)
