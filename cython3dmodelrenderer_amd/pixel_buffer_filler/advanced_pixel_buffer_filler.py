@@ -912,6 +912,12 @@ class AdvancedPixelBufferFiller:
                 break
         if only is None:
             self._host_fresh = True
+            # The arrays the caller holds show the buffers again — and are the caller's to write into from
+            # here on, getter call or not (they are the reference's buffers themselves, .pyx:246-253): the next
+            # compositing render carries them back first.  (Until round 5 only a getter call raised this flag:
+            # an edit made after a render_model, into arrays handed out before it, never reached the device.)
+            if self._host:
+                self._host_exposed = True
 
     def _mirror(self, name, buf):
         if not self._host_fresh:
