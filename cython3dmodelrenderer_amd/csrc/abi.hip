@@ -4,6 +4,7 @@
 // bin_pass (binning.hip) and raster_pass (raster.hip).
 #include "plan.h"
 
+#include <deque>
 #include <mutex>
 
 namespace crender_detail {
@@ -141,7 +142,13 @@ constexpr size_t kUsageSlotWords = 4 * (kUsageRing + 2);
 struct UsagePool {
     std::mutex m;
     uint32_t *host = nullptr;
-    std::vector<int> free_slots;
+    // FIFO: a slot given back is the LAST to be handed out again (1 023 other plans first) — a plan may be
+    // destroyed with a raster launch still in flight (destroying does not wait: a device synchronisation there
+    // cost every other filler's frames 0.3 ms), and that launch's record must not land in a live plan's slot.
+    // Each plan also salts the sequence word of its records (crender_plan::usage_salt): a record is only ever
+    // taken for the (plan, frame) that wrote it.
+    std::deque<int> free_slots;
+    uint32_t plans = 0;
 };
 UsagePool &usage_pool()
 {
@@ -149,7 +156,7 @@ UsagePool &usage_pool()
     return pool;
 }
 
-hipError_t usage_slot_take(uint32_t **host, uint32_t **dev, int *slot)
+hipError_t usage_slot_take(uint32_t **host, uint32_t **dev, int *slot, uint32_t *salt)
 {
     UsagePool &P = usage_pool();
     void *h = nullptr;
@@ -162,13 +169,15 @@ hipError_t usage_slot_take(uint32_t **host, uint32_t **dev, int *slot)
                                                hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable);
             if (e != hipSuccess) return e;
             P.host = static_cast<uint32_t *>(block);
-            for (int i = kUsageSlots - 1; i >= 0; --i) P.free_slots.push_back(i);
+            for (int i = 0; i < kUsageSlots; ++i) P.free_slots.push_back(i);
         }
         if (!P.free_slots.empty()) {
-            *slot = P.free_slots.back();
-            P.free_slots.pop_back();
+            *slot = P.free_slots.front();
+            P.free_slots.pop_front();
             h = P.host + (size_t)*slot * kUsageSlotWords;
         }
+        // (bit 31 set: salted with a frame number below 2^31 the word is never 0, a cleared record's value)
+        *salt = (++P.plans * 0x9E3779B1u) | 0x80000000u;
     }
     if (!h) {
         const hipError_t e = hipHostMalloc(&h, sizeof(uint32_t) * kUsageSlotWords, hipHostMallocMapped | hipHostMallocCoherent);
@@ -280,7 +289,7 @@ int crender_plan_create(crender_plan **out, int H, int W, int y0, int y1, int64_
     // slot of the process-wide pool (hipHostMalloc / hipHostFree per plan cost milliseconds, and the
     // free synchronises the device: a filler collected in the middle of another one's frames showed as
     // 0.3 ms per call)
-    if (e == hipSuccess) e = usage_slot_take(&p->usage, &p->usage_dev, &p->usage_slot);
+    if (e == hipSuccess) e = usage_slot_take(&p->usage, &p->usage_dev, &p->usage_slot, &p->usage_salt);
     if (e != hipSuccess) {
         delete p;
         return fail_hip(e, "crender_plan_create (workspace memset / pinned usage records)");
@@ -359,7 +368,7 @@ int crender_plan_poll_bin_usage(crender_plan *plan, uint64_t ticket, int64_t *ne
     const uint32_t *rec = plan->usage + 4 * slot;
     // the record is ONE aligned 16-byte store of the launch: whole, or not there yet
     const uint32_t seq = __atomic_load_n(rec, __ATOMIC_ACQUIRE);
-    if (seq != (uint32_t)ticket) return CRENDER_EBUSY;       // (not an error: no text)
+    if (seq != ((uint32_t)ticket ^ plan->usage_salt)) return CRENDER_EBUSY;       // (not an error: no text)
     usage_figures(plan, plan->usage_mode[slot], rec[1], rec[2], rec[3], needed, capacity);
     return CRENDER_OK;
 }

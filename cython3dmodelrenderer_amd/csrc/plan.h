@@ -86,6 +86,7 @@ struct crender_plan {
     uint32_t *usage = nullptr;            // [kUsageRing + 2][4] (the last two: staging of the blocking query)
     uint32_t *usage_dev = nullptr;        // the same memory as the device addresses it
     int usage_slot = -1;                  // its slot in the process-wide pool of pinned records (-1: an allocation of its own)
+    uint32_t usage_salt = 0;              // XORed into the sequence word of this plan's records (slots are recycled)
     uint64_t ticket = 0;                  // raster launches so far: the last frame's number
     unsigned char usage_mode[kUsageRing] = {};   // how the frame of each record was binned: 0 scan, 1 direct bins, 2 pair bins
     uint32_t *hint(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_hint) + 4 * k; }

@@ -1898,7 +1898,7 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     plan->usage_mode[uslot] = direct ? 1 : pairbins ? 2 : 0;
     tl.hdr = plan->hdr();
     tl.usage = plan->usage_dev + 4 * uslot;
-    tl.usage_seq = (uint32_t)plan->ticket;
+    tl.usage_seq = (uint32_t)plan->ticket ^ plan->usage_salt;
     const unsigned grid = (unsigned)(G.ntiles + tl.nhelp + (ordered ? 1 : 0));
     if constexpr (TS <= 32) {
         if (with_setup) {

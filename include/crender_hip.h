@@ -121,6 +121,10 @@ CRENDER_API size_t crender_plan_workspace_bytes(int H, int W, int y0, int y1, in
 CRENDER_API int crender_plan_create(crender_plan **out, int H, int W, int y0, int y1,
                         int64_t max_T, int64_t bin_capacity, int tile,
                         void *d_workspace, size_t workspace_bytes, void *stream);
+/* Destroying a plan does not wait for the device: launches of the plan still in flight finish on their own
+ * (the caller keeps the workspace valid until then, e.g. by freeing it in stream order); the pinned records
+ * they write into (crender_plan_poll_bin_usage) belong to a process-wide pool and are not handed to another plan
+ * until 1 023 others have been served. */
 CRENDER_API void crender_plan_destroy(crender_plan *plan);
 
 /* Synchronises `stream`, then reports the number of bin-list entries the most recent

@@ -2016,6 +2016,52 @@ def test_poll_bin_usage_c_abi(hip):
     assert lib.crender_plan_poll_bin_usage(plan.handle, 12, C.byref(need), C.byref(cap)) == _capi.EINVAL
 
 
+def test_usage_records_through_recycled_plans(hip, oracle):
+    """A plan's bin-usage records live in a slot of a process-wide pool of pinned memory that outlives it:
+    plans destroyed with their last launch still in flight (destroying does not wait), 1 100 of them one after
+    another — more than the pool has slots, so slots come round again — and every so often a plan that is
+    kept, whose frames must be reported with THEIR figures (a record is salted with its plan: a late store of
+    a dead plan can never pass for a live plan's) and rendered right."""
+    import ctypes as C
+    import torch
+    from cython3dmodelrenderer_amd import _capi
+    lib = _capi.load()
+    tri, col, nrm = scene("cube_inputs.npz")
+    t, c, n = _dev(tri), _dev(col), _dev(nrm)
+    H = W = 128
+    P = hip.projection_matrix(45.0, 0.1, 1000.0, H, W)
+    fb = hip.FrameBuffers(H, W)
+    ref = oracle.OracleFiller(H, W, fov=45.0)
+    ref.render_arrays(tri, col, nrm)
+    rng = np.random.default_rng(77)
+    stri, scol, snrm = random_soup(rng, 300, H, size_px=(30, 90), frac_backface=0.0)
+    st, sc, sn = _dev(stri), _dev(scol), _dev(snrm)
+    need, cap = C.c_int64(), C.c_int64()
+    for i in range(1100):
+        plan = hip.Plan(H, W, 12, tile=16)
+        hip.render_model(plan, t, c, n, P, fb, clear=True)
+        del plan                                  # (its launch may still be running)
+        if i % 137 == 0:
+            # a plan that overflows its 200-entry lists on the scan path: ITS record must say so
+            keep = hip.Plan(H, W, len(stri), tile=32, bin_capacity=200)
+            hip.render_model(keep, st, sc, sn, P, fb, clear=True, direct_bins=False)
+            k = lib.crender_plan_frame_ticket(keep.handle)
+            assert k == 1
+            torch.cuda.synchronize()
+            assert lib.crender_plan_poll_bin_usage(keep.handle, 1, C.byref(need), C.byref(cap)) == _capi.OK
+            assert need.value > cap.value == 200, (i, need.value, cap.value)
+            assert (need.value, cap.value) == keep.bin_usage()
+            del keep
+    plan = hip.Plan(H, W, 12, tile=16)
+    hip.render_model(plan, t, c, n, P, fb, clear=True)
+    torch.cuda.synchronize()
+    assert lib.crender_plan_poll_bin_usage(plan.handle, 1, C.byref(need), C.byref(cap)) == _capi.OK
+    assert need.value <= cap.value
+    z, cb, nb, _ = fb.numpy()
+    assert_bit_equal(z, ref.z_buffer, "after 1 100 recycled plans: z")
+    assert_bit_equal(cb, ref.color_buffer, "after 1 100 recycled plans: colour")
+
+
 def _plain_f32_vertex_normals(vertices, faces):
     """model.py:175-208 with every operation spelled out (no BLAS call): what the device kernels
     compute, on the host.  A dot of two float32 3-vectors = float32 products summed in float64 and
