@@ -23,6 +23,10 @@ def hip():
     return lowlevel
 
 
+# CRENDER_FUZZ_SOAK=n: n times the seeds of the session fuzz tests (a one-off soak; 1 in the committed runs)
+_SOAK = max(1, int(os.environ.get("CRENDER_FUZZ_SOAK", "1")))
+
+
 def _dev(a):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to("cuda:0")
@@ -392,7 +396,7 @@ def test_fuzz_random_configurations(hip, oracle, seed):
     assert_bit_equal(got[3][touched], f.winner[touched], what + ": winner")
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * _SOAK))
 def test_fuzz_many_frames_on_the_same_plans(hip, oracle, seed):
     """Seeded fuzz over what a plan CARRIES from frame to frame — counter parities, the split tiles' flag and
     helper-slot words, the dispatch-order hint, sticky overflow switches, bins filled and never drawn: one set
@@ -462,8 +466,8 @@ def test_fuzz_many_frames_on_the_same_plans(hip, oracle, seed):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("seed", range(24))
-def test_fuzz_a_filler_through_a_random_session(oracle, seed):
+@pytest.mark.parametrize("seed", range(24 * _SOAK))
+def test_fuzz_a_filler_through_a_random_session(oracle, hip, seed):
     """Seeded fuzz of the drop-in CLASS: one AdvancedPixelBufferFiller, forty-odd calls drawn at random —
     render_model on numpy models (composite, as the reference; or clear=True), render_arrays on device
     tensors, bursts of render_frame (with and without the swap chain, depth 1 or the default), clear(),
@@ -497,7 +501,12 @@ def test_fuzz_a_filler_through_a_random_session(oracle, seed):
             "small": random_soup(rng, 2500, max(H, W), size_px=(1, 9)),
             "large": random_soup(rng, 60, max(H, W), size_px=(20, 110)),
             "none": tuple(np.zeros((0, 3, 3), np.float32) for _ in range(3))}
+    if seed % 6 == 5:
+        # a model large enough for the filler's tile-coherent snapshot (2^18 triangles: sorted copy, (position,
+        # caller's index) pairs in the lists, winners found through the per-tile hash table)
+        pool["huge"] = random_soup(rng, 270_000, max(H, W), size_px=(0.5, 3))
     models = {k: M(*(a.copy() for a in v)) for k, v in pool.items()}
+    P = hip.projection_matrix(45.0, 0.1, 1000.0, H, W)
     names = list(pool)
     f = AdvancedPixelBufferFiller(H, W, fov=45, **kw)
     ref = oracle.OracleFiller(H, W, fov=45.0)
@@ -525,8 +534,8 @@ def test_fuzz_a_filler_through_a_random_session(oracle, seed):
     fresh = False          # the arrays handed out so far show the buffers: after a getter call, and after every
     #                        render_model, which refreshes them (.pyx:246-253: views of the buffers themselves)
     for step in range(44):
-        op = str(rng.choice(["model", "model", "model clear", "arrays", "frames", "clear", "check", "edit view",
-                             "edit view", "edit model"]))
+        op = str(rng.choice(["model", "model", "model clear", "arrays", "frames", "projected", "clear", "check",
+                             "edit view", "edit view", "edit model"]))
         name = names[int(rng.integers(0, len(names)))]
         story.append((op, name))
         if op == "model" or op == "model clear":
@@ -551,6 +560,14 @@ def test_fuzz_a_filler_through_a_random_session(oracle, seed):
                 continue
             for _ in range(int(rng.integers(1, 6))):
                 f.render_frame()
+            ref_clear()
+            ref.render_arrays(*resident, y0=strip[0], y1=strip[1])
+            fresh = False
+        elif op == "projected":
+            # a frame from ALREADY PROJECTED vertices (K2 alone) with the resident colours and normals
+            if resident is None or len(resident[0]) == 0 or f._order is not None:
+                continue
+            f.render_projected_frame(hip.project(_dev(resident[0]), P, W, H))
             ref_clear()
             ref.render_arrays(*resident, y0=strip[0], y1=strip[1])
             fresh = False
@@ -1144,7 +1161,7 @@ def test_renderer_with_illumination(oracle, direction):
     assert_bit_equal(img_f, f.color_buffer, "Renderer.render (illumination fused into the raster kernel)")
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * _SOAK))
 def test_fuzz_renderers_sharing_one_filler(oracle, seed):
     """Seeded sessions of ``Renderer.render`` (cy/renderer.py:47-49: render_model, draw_illumination on the
     WHOLE colour buffer, return it) through all four forms of this package's Renderer — numpy illumination on
@@ -2201,7 +2218,7 @@ def test_device_model_trex_from_the_mesh_to_the_golden_pixels(golden):
     assert sha(filler.get_winner_tensor().cpu().numpy()) == g["winner"]
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * _SOAK))
 def test_fuzz_a_device_model_moved_between_renders(oracle, seed):
     """Seeded sessions with a model that lives in HBM (DeviceModel): shifts and scales — HIP kernels that
     rewrite the by-triangle arrays in place and are bit-exact with the host Model's numpy — in between
