@@ -1503,6 +1503,39 @@ for H, W, cases in ((384, 512, [(e, c, "local") for e in ("planes", "color", "pr
             wants = (full.z_buffer, full.color_buffer, full.normals_buffer) if exchange == "planes" else (full.color_buffer,)
             for got, want in zip(out, wants):
                 assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), (H, exchange, chunks, project)
+# ---- a SESSION per strip renderer: the model changes every few frames (T-Rex, the cube's few large triangles,
+# a soup, no triangles), bursts of frames in between — every rank's plans, swap chain and exchange buffers carry
+# state from one model's frames into the next one's
+rng = np.random.default_rng(5)      # (the same soup on both ranks)
+def soup(n, lo, hi, res):
+    f = 2.4142137
+    cz = rng.uniform(0.5, 3.0, (n, 1)).astype(np.float32)
+    cxy = rng.uniform(-1.2 / f, 1.2 / f, (n, 2)).astype(np.float32) * cz
+    centre = np.concatenate([cxy, cz], 1)[:, None, :]
+    r = rng.uniform(lo, hi, (n, 1, 1)).astype(np.float32) * (2.0 / res) / f * cz[:, None, :]
+    t = (centre + rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32) * r).astype(np.float32)
+    nn = rng.standard_normal((n, 3, 3)).astype(np.float32); nn[..., 2] = -np.abs(nn[..., 2])
+    return t, rng.uniform(0, 255, (n, 3, 3)).astype(np.float32), nn
+cube = scenes.load_fixture("cube_inputs.npz")
+H, W = 320, 384
+pool = dict(trex=(tri, col, nrm), cube=cube, soup=soup(2500, 1, 12, W), few=soup(40, 20, 100, W))
+for exchange, chunks, project in (("planes", 1, "local"), ("planes", 3, "local"), ("color", 2, "broadcast"), ("present", 1, "local")):
+    sr = D.StripRenderer(H, W, rank, 2, fov=45, device="cuda:0", exchange=exchange, chunks=chunks, project=project)
+    for step, name in enumerate(["trex", "cube", "trex", "soup", "few", "cube", "soup", "trex", "few", "trex"]):
+        t, c, n = pool[name]
+        full = O.OracleFiller(H, W, fov=45)
+        full.render_arrays(t, c, n)
+        sr.set_model_arrays(t, c, n)
+        for _ in range(1 + step % 3):
+            out = sr.render_frame()
+        torch.cuda.synchronize()
+        what = ("session", exchange, chunks, project, step, name)
+        if exchange == "present":
+            assert np.array_equal(out[0].cpu().numpy(), full.color_buffer[::-1].astype("uint8")), what
+        else:
+            wants = (full.z_buffer, full.color_buffer, full.normals_buffer) if exchange == "planes" else (full.color_buffer,)
+            for got, want in zip(out, wants):
+                assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), what
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
