@@ -94,9 +94,9 @@ class Plan:
                                                       _stream(self.device)), "crender_plan_create")
 
     def __del__(self):
-        if getattr(self, "handle", None):
-            self._lib.crender_plan_destroy(self.handle)
-            self.handle = C.c_void_p()
+        handle, self.handle = getattr(self, "handle", None), None     # (at interpreter exit `C` may be gone already)
+        if handle:
+            self._lib.crender_plan_destroy(handle)
 
     def last_frame_direct(self):
         return bool(self._lib.crender_plan_last_frame_direct(self.handle))

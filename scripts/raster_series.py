@@ -52,6 +52,74 @@ def series(tag, pad_bytes):
     del fb, plan, pads
 
 
+if os.environ.get("ONE"):
+    # the three planes of a set carved from ONE allocation, `pad` bytes between them: is the launch's time then the
+    # same for every set, and which pad is the fast one?
+    plan = ll.Plan(H, W, T, device=dev)
+    ll.prepare(plan, t_tri, t_nrm, P)
+    keep = []
+    for pad in [int(v) for v in os.environ["ONE"].split(",")]:
+        row = []
+        for k in range(3):
+            nz, nc = H * W * 4, H * W * 12
+            big = torch.empty(nz + nc + nc + 2 * pad + 4096, dtype=torch.uint8, device=dev)
+            keep.append(big)
+            fb = ll.FrameBuffers(8, 8, device=dev, winner=False)
+            fb.h, fb.w = H, W
+            o1 = nz + pad; o2 = o1 + nc + pad
+            fb.z = big[0:nz].view(torch.float32).view(H, W)
+            fb.color = big[o1:o1 + nc].view(torch.float32).view(H, W, 3)
+            fb.normals = big[o2:o2 + nc].view(torch.float32).view(H, W, 3)
+            for _ in range(3):
+                ll.draw(plan, t_col, t_nrm, T, fb, clear=True)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(20):
+                ll.draw(plan, t_col, t_nrm, T, fb, clear=True)
+            b.record()
+            torch.cuda.synchronize()
+            row.append(a.elapsed_time(b) / 20)
+        print(f"{wl}: planes of a set in ONE allocation, {pad} B between them: ms per raster launch, three such sets: " + " ".join(f"{v:.4f}" for v in row))
+    sys.exit(0)
+if os.environ.get("SETS"):
+    # K framebuffer sets alive at once (distinct memory), the same plan: does the launch's time belong to the SET?
+    K = int(os.environ["SETS"])
+    plan = ll.Plan(H, W, T, device=dev)
+    ll.prepare(plan, t_tri, t_nrm, P)
+    sets = [ll.FrameBuffers(H, W, device=dev, winner=False) for _ in range(K)]
+    for rnd in range(3):
+        row = []
+        for fb in sets:
+            for _ in range(3):
+                ll.draw(plan, t_col, t_nrm, T, fb, clear=True)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(20):
+                ll.draw(plan, t_col, t_nrm, T, fb, clear=True)
+            b.record()
+            torch.cuda.synchronize()
+            row.append(a.elapsed_time(b) / 20)
+        print(f"{wl} round {rnd}: ms per raster launch into each of {K} framebuffer sets alive at once: " + " ".join(f"{v:.4f}" for v in row))
+    print("   z planes at " + " ".join(hex(fb.z.data_ptr()) for fb in sets))
+    print("   colour planes at " + " ".join(hex(fb.color.data_ptr()) for fb in sets))
+    # and a pure fill of each set (the fused clear alone: no triangles) — the store pattern without the coverage work
+    e = torch.zeros((0, 3, 3), dtype=torch.float32, device=dev)
+    plan0 = ll.Plan(H, W, 1, device=dev)
+    row = []
+    for fb in sets:
+        ll.render_model(plan0, e, e, e, P, fb, clear=True)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(20):
+            ll.render_model(plan0, e, e, e, P, fb, clear=True)
+        b.record()
+        torch.cuda.synchronize()
+        row.append(a.elapsed_time(b) / 20)
+    print(f"{wl}: ms per EMPTY frame (fused clear of every tile) into each set: " + " ".join(f"{v:.4f}" for v in row))
+    sys.exit(0)
 series("first allocation", 0)
 series("second allocation, same sizes", 0)
 series("planes 1 MiB + 4 KiB further apart", (1 << 20) + 4096)
