@@ -323,6 +323,10 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the next frame's bin pass with this frame's raster pass")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
+    ap.add_argument("--raster-path", default="auto", choices=["auto", "0", "1", "2"],
+                    help="which raster kernel 32-pixel plans use: auto = each plan's own choice from the size classes "
+                         "its previous frames counted (the product's default), 0 general, 1 pixel owners only, "
+                         "2 small records only — every one exact on every tile (A/B knob)")
     ap.add_argument("--pipeline-depth", type=int, default=0,
                     help="frames in flight (swap-chain depth); 0 = the filler's choice")
     ap.add_argument("--lookahead", default="auto", choices=["auto", "on", "off"],
@@ -388,6 +392,7 @@ def main():
         tri, col, nrm = tri[:args.max_triangles], col[:args.max_triangles], nrm[:args.max_triangles]
     T = int(tri.shape[0])
     strips = world > 1 and args.mode == "strips"
+    rpath = None if args.raster_path == "auto" else int(args.raster_path)
     y0, y1 = D.strip_rows(H, world, rank) if strips else (0, H)
     if strips:
         sr = D.StripRenderer(H, W, rank, world, fov=fov, device=device, tile=args.tile,
@@ -399,7 +404,8 @@ def main():
         filler = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=args.tile,
                                            pipeline=not args.no_pipeline,
                                            pipeline_depth=args.pipeline_depth,
-                                           lookahead={"auto": None, "on": True, "off": False}[args.lookahead])
+                                           lookahead={"auto": None, "on": True, "off": False}[args.lookahead],
+                                           raster_path=rpath)
 
     if args.pipeline_tile:
         filler._pipeline_tile = args.pipeline_tile       # (A/B knob: the chain's own choice otherwise)
@@ -485,7 +491,7 @@ def main():
     kframe_events_ms = kframe_b2b_ms = None
     if lookahead:
         probe = AdvancedPixelBufferFiller(H, W, fov=fov, device=device, tile=filler._pipe.tile, pipeline=True,
-                                          pipeline_depth=1, lookahead=True,
+                                          pipeline_depth=1, lookahead=True, raster_path=rpath,
                                           row_strip=(y0, y1) if strips else None)
         probe.render_arrays(tri, col, nrm, clear=True)
         probe.synchronize()
@@ -505,6 +511,7 @@ def main():
             probe.render_frame()
         n_k, kframe_events_ms = probe._pipe.timing_end()
         assert n_k == args.steps and not probe._pipe.overflowed(probe)
+        probe_paths = probe.last_raster_paths()
         del probe
 
     # ---- strips: the SAME frame on ONE GPU, in the same run (rank 0; the others wait at the next
@@ -565,12 +572,15 @@ def main():
         single_ms = elapsed_single / args.steps * 1e3
         raster_b2b_ms = max(single_ms - bin_ms, 0.0)
         ts = (filler._pipe.tile if lookahead else filler.tile) or (16 if H * W <= 1024 * 1024 else 32)
+        # (32-pixel plans have three raster kernels, all exact; which one these launches were: the plans say)
+        paths = filler.last_raster_paths()
+        kpath = (probe_paths[-1] if lookahead else paths[0]) if ts == 32 else 0
         if lookahead:
-            kernel = f"k_frame<{ts},true>"
+            kernel = f"k_frame<{ts},true,{kpath}>"
             views = {"hip_events_around_each_launch": kframe_events_ms, "frames_back_to_back_on_one_stream": kframe_b2b_ms}
             prof = load_rocprof_avg_ms(args.workload, "k_frame_one_stream") if rows == H else None
         else:
-            kernel = f"k_raster<{ts},true>"
+            kernel = f"k_raster<{ts},true,{kpath}>"
             views = {"hip_events_around_each_launch": raster_ms,
                      "single_stream_frame_minus_event_measured_bin_passes": raster_b2b_ms}
             prof = load_rocprof_avg_ms(args.workload, "k_raster") if rows == H else None
@@ -600,6 +610,9 @@ def main():
                                      if strips else "independent full frames per rank, no collective"),
                        "tile": filler.tile or "auto",
                        "pipeline_tile": filler._pipe.tile if filler._pipe is not None else None,
+                       "raster_path": {"asked": args.raster_path, "last_launch_of_each_plan": paths,
+                                       "what": "0 general kernel, 1 pixel owners only, 2 small records (row spans) only; "
+                                               "auto: each plan picks by the tile size classes its previous frames counted"},
                        "frame": "clear + project + rasterize, model resident in HBM",
                        "pipelined": (False if args.no_pipeline else
                                      f"swap chain of {filler._pipeline_depth} (GPU_MAX_HW_QUEUES="

@@ -10,13 +10,15 @@ import os
 
 from . import _build
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OK, EINVAL, EHIP, ENOMEM, EBUSY = 0, 1, 2, 3, 4
 FUSED_CLEAR = 1
 NO_DIRECT_BINS = 2
 OVERLAPPED_FRAMES = 4
 FUSED_GURO = 8
 STATIC_INPUTS = 16
+# raster kernels of a 32-pixel plan (crender_plan_set_raster_path): all exact on every tile
+PATH_AUTO, PATH_GENERAL, PATH_OWNERS, PATH_SMALL = -1, 0, 1, 2
 
 _vp, _i32, _i64, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint, C.c_size_t
 _f32p = C.POINTER(C.c_float)
@@ -38,6 +40,9 @@ SIGNATURES = {
     "crender_plan_frame_ticket": (C.c_uint64, [_vp]),
     "crender_plan_poll_bin_usage": (_i32, [_vp, C.c_uint64, C.POINTER(_i64), C.POINTER(_i64)]),
     "crender_plan_set_light": (_i32, [_vp, _f32p]),
+    "crender_plan_set_raster_path": (_i32, [_vp, _i32]),
+    "crender_plan_last_raster_path": (_i32, [_vp]),
+    "crender_set_default_raster_path": (_i32, [_i32]),
     "crender_plan_set_triangle_order": (_i32, [_vp, _vp, _vp]),
     "crender_plan_set_normal_z": (_i32, [_vp, _vp]),
     "crender_tile_order_keys": (_i32, [_vp, _i64, _f32p, _i32, _i32, _vp, _vp]),
@@ -102,6 +107,12 @@ def load():
     got = L.crender_abi_version()
     if got != ABI_VERSION:
         raise CrenderError(f"libcrender_hip.so ABI {got}, binding expects {ABI_VERSION}")
+    # CRENDER_RASTER_PATH=0|1|2: every plan that has not been told otherwise renders with that kernel
+    # (crender_set_default_raster_path) — how the parity suite is run once per kernel
+    forced = os.environ.get("CRENDER_RASTER_PATH")
+    if forced not in (None, ""):
+        if L.crender_set_default_raster_path(int(forced)) != OK:
+            raise CrenderError(f"CRENDER_RASTER_PATH={forced}: expected -1, 0, 1 or 2")
     _lib = L
     return L
 

@@ -4,12 +4,15 @@
 // bin_pass (binning.hip) and raster_pass (raster.hip).
 #include "plan.h"
 
+#include <atomic>
 #include <deque>
 #include <mutex>
 
 namespace crender_detail {
 
 thread_local std::string g_last_error;
+static std::atomic<int> g_default_path{-1};
+int default_raster_path() { return g_default_path.load(std::memory_order_relaxed); }
 
 int fail(int code, const char *what)
 {
@@ -90,6 +93,7 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
     // small frames are dispatched in the order the previous frame suggests (build_order)
     L.ordered = (L.ts == 16 || (L.ts == 32 && L.g.ntiles <= 2048)) && L.direct_cap > 0 && L.g.ntiles <= kOrderMaxTiles;
     L.off_hint = o;    o = align_up(o + sizeof(uint32_t) * 8);                      // two headers of 4 words
+    L.off_stats = o;   o = align_up(o + sizeof(uint32_t) * 2 * kStatWords);         // tile size classes, two parities
     L.off_order = o;   o = align_up(o + sizeof(uint32_t) * 2 * (size_t)(L.ordered ? L.g.ntiles : 0));
     L.off_grouped = o; o = align_up(o + 2 * (size_t)(L.ordered ? L.g.ntiles : 0));
     L.off_offs = o;    o = align_up(o + sizeof(uint32_t) * (size_t)(L.g.ntiles + 1));
@@ -138,7 +142,7 @@ int tile_frame(crender_plan *plan, bool project, const float *d_tri, const float
 // its own.
 void usage_slot_give(uint32_t *host, int slot);
 constexpr int kUsageSlots = 1024;
-constexpr size_t kUsageSlotWords = 4 * (kUsageRing + 2);
+constexpr size_t kUsageSlotWords = kUsageWords * (kUsageRing + 1);
 struct UsagePool {
     std::mutex m;
     uint32_t *host = nullptr;
@@ -152,7 +156,10 @@ struct UsagePool {
 };
 UsagePool &usage_pool()
 {
-    static UsagePool pool;
+    // leaked on purpose: crender_plan_destroy may run from a static destructor or a Python __del__ AFTER the
+    // process's atexit handlers, and must still find the mutex and the queue alive (the pinned block is never
+    // freed anyway)
+    static UsagePool &pool = *new UsagePool;
     return pool;
 }
 
@@ -348,7 +355,7 @@ int crender_plan_last_bin_usage(crender_plan *plan, void *stream, int64_t *neede
 {
     if (!plan) return fail(CRENDER_EINVAL, "null plan");
     // (into the plan's own pinned memory: a pageable destination makes the runtime stage the copy)
-    volatile uint32_t *h = plan->usage + 4 * kUsageRing;       // (the two records behind the ring)
+    volatile uint32_t *h = plan->usage + kUsageWords * kUsageRing;       // (the record behind the ring)
     hipStream_t s = static_cast<hipStream_t>(stream);
     CR_HIP(hipMemcpyAsync(const_cast<uint32_t *>(h), plan->hdr(), 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     CR_HIP(hipStreamSynchronize(s));
@@ -365,11 +372,15 @@ int crender_plan_poll_bin_usage(crender_plan *plan, uint64_t ticket, int64_t *ne
         return fail(CRENDER_EINVAL, "crender_plan_poll_bin_usage: no such frame (not launched yet, or more than "
                                     "8 frames ago: its record has been reused)");
     const int slot = (int)(ticket % kUsageRing);
-    const uint32_t *rec = plan->usage + 4 * slot;
-    // the record is ONE aligned 16-byte store of the launch: whole, or not there yet
-    const uint32_t seq = __atomic_load_n(rec, __ATOMIC_ACQUIRE);
-    if (seq != ((uint32_t)ticket ^ plan->usage_salt)) return CRENDER_EBUSY;       // (not an error: no text)
-    usage_figures(plan, plan->usage_mode[slot], rec[1], rec[2], rec[3], needed, capacity);
+    const volatile uint32_t *rec = plan->usage + kUsageWords * slot;
+    // the record is two aligned 16-byte stores of the launch, the frame's sequence word leading the first
+    // and trailing the second: taken only when BOTH are there (a record half landed reads as not landed)
+    const uint32_t want = (uint32_t)ticket ^ plan->usage_salt;
+    if (__atomic_load_n(const_cast<const uint32_t *>(rec), __ATOMIC_ACQUIRE) != want || rec[7] != want)
+        return CRENDER_EBUSY;                                                      // (not an error: no text)
+    const uint32_t h0 = rec[1], h1 = rec[2], h4 = rec[3];
+    if (rec[0] != want || rec[7] != want) return CRENDER_EBUSY;                    // (rewritten under the read: a frame 8 later)
+    usage_figures(plan, plan->usage_mode[slot], h0, h1, h4, needed, capacity);
     return CRENDER_OK;
 }
 
@@ -393,6 +404,22 @@ int crender_plan_set_light(crender_plan *plan, const float *light3)
 {
     if (!plan || !light3) return fail(CRENDER_EINVAL, "crender_plan_set_light: bad argument");
     plan->light[0] = light3[0]; plan->light[1] = light3[1]; plan->light[2] = light3[2];
+    return CRENDER_OK;
+}
+
+int crender_plan_set_raster_path(crender_plan *plan, int path)
+{
+    if (!plan || path < -1 || path > 2) return fail(CRENDER_EINVAL, "crender_plan_set_raster_path: path is -1 (automatic), 0, 1 or 2");
+    plan->forced_path = path;
+    return CRENDER_OK;
+}
+
+int crender_plan_last_raster_path(crender_plan *plan) { return plan ? plan->last_path : 0; }
+
+int crender_set_default_raster_path(int path)
+{
+    if (path < -1 || path > 2) return fail(CRENDER_EINVAL, "crender_set_default_raster_path: path is -1 (automatic), 0, 1 or 2");
+    g_default_path.store(path, std::memory_order_relaxed);
     return CRENDER_OK;
 }
 

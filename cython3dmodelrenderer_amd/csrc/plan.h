@@ -20,10 +20,13 @@ struct Layout {
     int hmax;             // helper triples of a raster launch (heavy tiles split in four), 0 = none
     bool ordered;         // raster launches leave a dispatch order for the next one (build_order)
     size_t count_stride;  // u32 words between the two parities of the per-tile counters
-    size_t off_hdr, off_count, off_hflag, off_hslots, off_hint, off_order, off_grouped, off_offs,
+    size_t off_hdr, off_count, off_hflag, off_hslots, off_hint, off_stats, off_order, off_grouped, off_offs,
            off_trange, off_proj, off_entries, off_direct, off_pairbins, total;
 };
 constexpr int kUsageRing = 8;
+constexpr int kUsageWords = 8;         // words per usage record: {seq, hdr[0], hdr[1], hdr[4]} {large, small, path, seq}
+constexpr int kStatWords = 2 * 16;     // per parity: kStatSlots (large, small) pairs (raster.hip, TileLists::stats)
+int default_raster_path();             // crender_set_default_raster_path (-1: none)
 constexpr int kOrderMaxTiles = 8192;   // ordered dispatch: the builder keeps one byte per tile in the batch queue's LDS
 constexpr int kMaxHeavyHelped32 = 512;
 constexpr int kMaxHeavyHelped = 128;   // +384 workgroups per raster launch (9 % at 1024 x 1024)
@@ -83,12 +86,16 @@ struct crender_plan {
     // own in PINNED host memory the plan owns — one 16-byte store by one thread of the launch,
     // {frame number, hdr[0], hdr[1], hdr[4]} — so that the host learns of an overflow by reading its
     // own memory: no copy command, no event, no synchronisation.  Ring of kUsageRing frames.
-    uint32_t *usage = nullptr;            // [kUsageRing + 2][4] (the last two: staging of the blocking query)
+    uint32_t *usage = nullptr;            // [kUsageRing + 1][kUsageWords] (the last one: staging of the blocking query)
     uint32_t *usage_dev = nullptr;        // the same memory as the device addresses it
     int usage_slot = -1;                  // its slot in the process-wide pool of pinned records (-1: an allocation of its own)
     uint32_t usage_salt = 0;              // XORed into the sequence word of this plan's records (slots are recycled)
     uint64_t ticket = 0;                  // raster launches so far: the last frame's number
     unsigned char usage_mode[kUsageRing] = {};   // how the frame of each record was binned: 0 scan, 1 direct bins, 2 pair bins
+    // which raster kernel a 32-pixel plan's frames get (raster.hip, kPath*): forced by the caller (-1: not),
+    // else suggested by the size classes its last reported frame counted; what the last launch was
+    int forced_path = -1, auto_path = 0, last_path = 0;
+    uint32_t *stats(int par) const { return reinterpret_cast<uint32_t *>(ws + L.off_stats) + (size_t)par * kStatWords; }
     uint32_t *hint(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_hint) + 4 * k; }
     uint32_t *order(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_order) + (size_t)k * L.g.ntiles; }
     unsigned char *grouped(int k) const { return ws + L.off_grouped + (size_t)k * L.g.ntiles; }

@@ -73,6 +73,18 @@ CR_DEV void lds_key_min(unsigned long long *slot, unsigned long long k)
     __hip_atomic_fetch_min(slot, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Three kernels render a 32-pixel plan's tiles, ALL of them exact on every tile (the parity tests force each
+// one through every scene): the general one with every path in it, and two with one path each and the
+// registers / LDS that path needs —
+//   owners  every batch goes to the pixel owners (frames of large triangles: bunny 4096^2, T-Rex 8192^2);
+//           no key plane, no prefix sums: 19.5 KB of LDS and 7 wavefronts per SIMD instead of 6;
+//   small   every batch goes through the run-wise sweep over EXACT ROW SPANS (frames of small triangles:
+//           the 10 M-triangle soup, T-Rex 1024^2 on 32-pixel tiles): 31.8 KB of LDS, 5 workgroups per CU.
+// Which one a frame gets is a hint about speed only (run_raster_pass: the size class the previous frames'
+// tiles reported, or crender_plan_set_raster_path).
+enum { kPathGeneral = 0, kPathOwners = 1, kPathSmall = 2 };
+constexpr int kStatSlots = 16;
+
 // One batch of (tile, triangle) work in LDS, struct-of-arrays, slot = thread index.
 // A record's pixel box (clipped to the tile) is cut into work items numbered row-major:
 // 4x4-pixel blocks on 32/64-pixel tiles, single pixels on 16-pixel tiles; blk_scan holds the
@@ -431,6 +443,14 @@ struct TileLists {
     const uint32_t *hdr;
     uint32_t *usage;
     uint32_t usage_seq;
+    // Size class of this frame's covered tiles, counted by the tiles' own workgroups (32-pixel plans): per
+    // covered tile one non-returning atomic into one of kStatSlots (large, small) pairs — is the first
+    // wavefront's share of the list, on average, records of 16 blocks and more (the pixel owners' kind) or
+    // smaller ones (the run-wise sweep's)?  The launch's record carries the sums of the PREVIOUS launch on
+    // the plan (complete by then: launches of a plan follow each other on a stream) and zeroes them; the
+    // host picks the next launches' kernel by them (raster_path_hint).  A hint about speed only.
+    uint32_t *stats, *stats_prev;
+    uint32_t path;              // which kernel this launch is (kPath*): goes into the record
 };
 
 // One record of a tile's list: projected vertices, triangle index AS THE CALLER KNOWS IT (what depth
@@ -466,6 +486,12 @@ CR_DEV bool load_record(const TileLists &L, const float *__restrict__ proj, cons
     if (id >= L.T) return false;
     if (L.orig_of) id = L.orig_of[id];
     return true;
+}
+
+// One covered tile's size class into the frame's statistics (see TileLists::stats): called by one lane.
+CR_DEV void count_tile_class(const TileLists &L, bool large)
+{
+    if (L.stats) atomicAdd(&L.stats[(((blockIdx.x >> 3) & (kStatSlots - 1)) << 1) + (large ? 0u : 1u)], 1u);
 }
 
 // ---- dispatch order from the previous frame's coverage -------------------------------------
@@ -572,8 +598,8 @@ CR_DEV void build_order(const uint32_t *__restrict__ count, int ntx, int nty,
 // second set of divisions.  Same device functions, same keys, same tie rule as the sweeps above:
 // the planes are bit-identical.
 constexpr uint32_t kOwnFast = 1u << 4;     // flags word of a record: bits 0..3 bands, 4 window, 5..10 signs
-template <bool CLEAR, typename I>
-CR_DEV void owner_tile(const WorkQueue &q, const float *pre, int nrec, const float *__restrict__ col, const float *__restrict__ nrm,
+template <bool CLEAR, typename I, typename Q>
+CR_DEV void owner_tile(const Q &q, const float *pre, int nrec, const float *__restrict__ col, const float *__restrict__ nrm,
                        const uint32_t *__restrict__ pos_of, const Light &Lt,
                        float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
                        int32_t *__restrict__ win, int W, int X0, int Y0, int X1, int Y1)
@@ -761,6 +787,7 @@ constexpr size_t raster_queue_bytes()
 {
     return TS == 16 ? sizeof(Rec16) * kBatch16 + sizeof(uint32_t) * (kThreads + 8) : sizeof(WorkQueue);
 }
+// (the kernels with one path each, kPathOwners / kPathSmall, size theirs themselves: path_queue_bytes below)
 
 // Which tile workgroup `b` of a raster launch takes, and which part of it; false: the workgroup is done
 // (it built the dispatch order, found its helper slot empty, or cleared its group of empty tiles).
@@ -830,8 +857,24 @@ CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad
             *L.hint_bad_next = 0;
         }
         if (m == G.ntiles - 1 && tid == 0) {
-            // (the binning pass that wrote these words ran in an earlier launch of the stream)
-            *reinterpret_cast<uint4 *>(L.usage) = make_uint4(L.usage_seq, L.hdr[0], L.hdr[1], L.hdr[4]);
+            // (the binning pass that wrote these words ran in an earlier launch of the stream; so did the
+            // launch that counted into stats_prev)
+            uint32_t nl = 0, ns = 0;
+            if (L.stats_prev) {
+                uint4 v[kStatSlots / 2];
+#pragma unroll
+                for (int i = 0; i < kStatSlots / 2; ++i) v[i] = reinterpret_cast<const uint4 *>(L.stats_prev)[i];
+#pragma unroll
+                for (int i = 0; i < kStatSlots / 2; ++i) {
+                    nl += v[i].x + v[i].z; ns += v[i].y + v[i].w;
+                    reinterpret_cast<uint4 *>(L.stats_prev)[i] = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+            // two aligned 16-byte stores; the sequence word leads the first and TRAILS the second: the
+            // reader takes the record only when both are this frame's
+            uint4 *rec = reinterpret_cast<uint4 *>(L.usage);
+            rec[1] = make_uint4(nl, ns, L.path, L.usage_seq);
+            rec[0] = make_uint4(L.usage_seq, L.hdr[0], L.hdr[1], L.hdr[4]);
         }
         if (L.order && L.hint[0] && !*L.hint_bad) {
             const int ns = (int)L.hint[1], ng = (int)L.hint[2];
@@ -1165,12 +1208,509 @@ CR_DEV void owner_path32(const Tile<32> &c, int nrec)
     }
     __syncthreads();
     if (L.addr32)
-        owner_tile<CLEAR, uint32_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, zb, cb, nb, win,
-                                    G.W, X0, Y0, X1, Y1);
+        owner_tile<CLEAR, uint32_t, WorkQueue>(q, pre, nrec, col, nrm, L.pos_of, L.light, zb, cb, nb, win,
+                                               G.W, X0, Y0, X1, Y1);
     else
-        owner_tile<CLEAR, size_t>(q, pre, nrec, col, nrm, L.pos_of, L.light, zb, cb, nb, win,
-                                  G.W, X0, Y0, X1, Y1);
+        owner_tile<CLEAR, size_t, WorkQueue>(q, pre, nrec, col, nrm, L.pos_of, L.light, zb, cb, nb, win,
+                                             G.W, X0, Y0, X1, Y1);
     CR_STAMP(3);
+}
+
+// ---- the owners' kernel (kPathOwners): every batch of every tile goes to the pixel owners -----------------
+// What the pixel owners need of a batch, and nothing else: nine coordinates, index, clipped box (11 KB) and
+// the eight per-record words of owner_path32 (8 KB) — no key plane, no prefix sums, no second sweep in the
+// kernel: 19.5 KB of LDS and (kernel_regs.py) 7 wavefronts per SIMD.  Exact on EVERY tile, whatever its
+// records: a list of more than one batch (rare where this kernel is chosen) keeps the pixels' running
+// minimum keys in registers across the batches and stores, after each batch, the pixels that batch won
+// (a later batch's winner writes the pixel again: same thread, program order); the background last.
+struct OwnerQueue {
+    float x0[kThreads], y0[kThreads], z0[kThreads];
+    float x1[kThreads], y1[kThreads], z1[kThreads];
+    float x2[kThreads], y2[kThreads], z2[kThreads];
+    uint32_t tri[kThreads];
+    uint32_t box[kThreads];      // pack_box
+};
+// One batch of the owners' kernel into LDS: the thread's record (clipped box, coordinates, index) and its
+// eight words — denominators, reciprocals, signs, window flag, and which of the four wavefronts' bands of
+// eight rows the triangle can touch at all (owner_path32's, here straight from the registers the record
+// was loaded into: no barrier between the queue and the words).
+CR_DEV void owners_queue(const Tile<32> &c, uint32_t base, bool first)
+{
+    [[maybe_unused]] constexpr int TS = 32;
+    CR_TILE_LOCALS(c);
+    OwnerQueue &oq = *reinterpret_cast<OwnerQueue *>(qraw);
+    float *pre = reinterpret_cast<float *>(key);
+    uint32_t id = 0, ebx = 0, eby = 0;
+    TriXYZ t{};
+    bool ok = base + tid < end;
+    if (ok) ok = load_record(L, proj, G, base + tid, id, t, ebx, eby);
+    uint32_t box_xy = 0, box_wh = 0;
+    if (ok) {
+        int xl = (int)(ebx & 0xFFFF), xr = (int)(ebx >> 16);
+        int yt = (int)(eby & 0xFFFF), yb = (int)(eby >> 16);
+        if (xl < X0) xl = X0;
+        if (xr > X1) xr = X1;
+        if (yt < Y0) yt = Y0;
+        if (yb > Y1) yb = Y1;
+        if (xl < xr && yt < yb) {
+            box_xy = (uint32_t)xl | ((uint32_t)yt << 16);
+            box_wh = (uint32_t)(xr - xl) | ((uint32_t)(yb - yt) << 16);
+        }
+    }
+    if (first && wave == 0) {      // the tile's size class (TileLists::stats)
+        const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_sum((uint32_t)blocks_of(box_wh)), 63);
+        const uint32_t n0 = end - beg < 64u ? end - beg : 64u;
+        if (lane == 0) count_tile_class(L, tot0 >= 16u * n0);
+    }
+    if (!first) __syncthreads();    // the previous batch's readers are done with the queue
+    oq.x0[tid] = t.x0; oq.y0[tid] = t.y0; oq.z0[tid] = t.z0;
+    oq.x1[tid] = t.x1; oq.y1[tid] = t.y1; oq.z1[tid] = t.z1;
+    oq.x2[tid] = t.x2; oq.y2[tid] = t.y2; oq.z2[tid] = t.z2;
+    oq.tri[tid] = id;
+    oq.box[tid] = pack_box(box_xy, box_wh, X0, Y0);
+    uint32_t flags = 0;
+    const TriSetup st = make_setup(t, true);
+    if (box_wh != 0) {
+        flags = st.fast ? kOwnFast : 0u;
+        flags |= (uint32_t)(st.rej1 > 0.0f ? 1 : st.rej1 < 0.0f ? 2 : 0) << 5;
+        flags |= (uint32_t)(st.rej2 > 0.0f ? 1 : st.rej2 < 0.0f ? 2 : 0) << 7;
+        flags |= (uint32_t)(st.rej3 > 0.0f ? 1 : st.rej3 < 0.0f ? 2 : 0) << 9;
+        const int bx0 = (int)(box_xy & 0xFFFF), by0 = (int)(box_xy >> 16);
+        const int bx1 = bx0 + box_w(box_wh), by1 = by0 + box_h(box_wh);
+#pragma unroll
+        for (int band = 0; band < 4; ++band) {
+            const int ya = Y0 + 8 * band, yb = (ya + 8 < Y1) ? ya + 8 : Y1;
+            if (by1 > ya && by0 < yb &&
+                !rect_surely_missed(st, bx0, bx1 - 1, by0 > ya ? by0 : ya, (by1 < yb ? by1 : yb) - 1))
+                flags |= 1u << band;
+        }
+    }
+    float4 *o = reinterpret_cast<float4 *>(pre + 8 * tid);
+    o[0] = make_float4(st.l03, st.l13, st.l23, __uint_as_float(flags));
+    o[1] = make_float4(st.fast ? st.r1 : 0.0f, st.r2, st.r3, 0.0f);
+    __syncthreads();
+}
+
+// A list of more than one batch (rare where this kernel is chosen; this path may spill, the one-batch
+// path — owner_tile — must not): the pixels' running minimum keys stay in registers across the batches.
+template <bool CLEAR, typename I>
+CR_DEV void owners_batches(const Tile<32> &c)
+{
+    [[maybe_unused]] constexpr int TS = 32;
+    CR_TILE_LOCALS(c);
+    OwnerQueue &oq = *reinterpret_cast<OwnerQueue *>(qraw);
+    float *pre = reinterpret_cast<float *>(key);
+    constexpr int XS = 8;
+    const int Xs = X0 + (tid & 7), Y = Y0 + (tid >> 3);
+    const bool mine_in = Y < Y1 && Xs < X1;
+    const I pix0 = (I)((I)Y * (I)G.W + (I)Xs);
+    unsigned long long best[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        best[j] = make_key(zord(1e6f), KEY_LOW_PRIOR);
+        if (!CLEAR && Y < Y1 && Xs + XS * j < X1) best[j] = make_key(zord_prior(*elem(zb, (I)(pix0 + XS * j))), KEY_LOW_PRIOR);
+    }
+    const uint32_t my_band = 1u << (tid >> 6);
+    for (uint32_t base = beg; base < end; base += kThreads) {
+        owners_queue(c, base, base == beg);
+        if (base == beg) CR_STAMP(6);
+        const int nrec = (int)((end - base) < (uint32_t)kThreads ? (end - base) : (uint32_t)kThreads);
+        // ---- the owners walk the batch (owner_tile's loop) ---------------------------------------------
+        float w1[4], w2[4], w3[4];          // the barycentrics of the pixels this batch wins
+        uint32_t slots = 0, won = 0;        // their record slots, one byte per pixel; which of the four
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w1[j] = w2[j] = w3[j] = 0.0f;
+        for (int r = 0; r < nrec; ++r) {
+            const float4 p0 = *reinterpret_cast<const float4 *>(pre + 8 * r);
+            const uint32_t flags = __float_as_uint(p0.w);
+            if (!(flags & my_band)) continue;           // (uniform over the wavefront)
+            const uint32_t pb = oq.box[r];
+            const uint32_t wh = packed_wh(pb), xy = packed_xy(pb, X0, Y0);
+            const int bx0 = (int)(xy & 0xFFFF), by0 = (int)(xy >> 16);
+            const int bx1 = bx0 + box_w(wh), by1 = by0 + box_h(wh);
+            TriSetup st;
+            {
+                const float4 p1 = *reinterpret_cast<const float4 *>(pre + 8 * r + 4);
+                st.x0 = oq.x0[r]; st.y0 = oq.y0[r]; st.z0 = oq.z0[r];
+                st.x1 = oq.x1[r]; st.y1 = oq.y1[r]; st.z1 = oq.z1[r];
+                st.x2 = oq.x2[r]; st.y2 = oq.y2[r]; st.z2 = oq.z2[r];
+                st.l01 = st.x1 - st.x2; st.l02 = st.y1 - st.y2;
+                st.l11 = st.x2 - st.x0; st.l12 = st.y2 - st.y0;
+                st.l21 = st.x0 - st.x1; st.l22 = st.y0 - st.y1;
+                st.l03 = p0.x; st.l13 = p0.y; st.l23 = p0.z; st.fast = (flags & kOwnFast) != 0;
+                st.r1 = p1.x; st.r2 = p1.y; st.r3 = p1.z;
+                auto sign_of = [](uint32_t two_bits) { return two_bits == 1u ? 1.0f : two_bits == 2u ? -1.0f : 0.0f; };
+                st.rej1 = sign_of((flags >> 5) & 3u); st.rej2 = sign_of((flags >> 7) & 3u); st.rej3 = sign_of((flags >> 9) & 3u);
+            }
+            const uint32_t low = 0xFFFFFFFEu - oq.tri[r];
+            const bool rows_ok = Y >= by0 && Y < by1;
+            const float fy = (float)Y;
+            const float ry1 = st.l01 * (fy - st.y2), ry2 = st.l11 * (fy - st.y0), ry3 = st.l21 * (fy - st.y1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (X0 + XS * j >= bx1 || X0 + XS * j + XS <= bx0) continue;     // the box misses block j (uniform)
+                const int x = Xs + XS * j;
+                const float fx = (float)x;
+                const float n1 = ry1 - st.l02 * (fx - st.x2), n2 = ry2 - st.l12 * (fx - st.x0), n3 = ry3 - st.l22 * (fx - st.x1);
+                const bool live = rows_ok && (unsigned)(x - bx0) < (unsigned)(bx1 - bx0) && !surely_outside(st, n1, n2, n3);
+                if (wave_any(live)) {
+                    if (live) {
+                        float b1, b2, b3;
+                        quotients(st, n1, n2, n3, true, b1, b2, b3);
+                        if (!(b1 < 0.0f || b2 < 0.0f || b3 < 0.0f)) {          // .pyx:215-216 (NaN passes)
+                            const float z = interp(st.z0, st.z1, st.z2, b1, b2, b3);
+                            if (z == z) {                                      // .pyx:220
+                                const unsigned long long k = make_key(zord(z), low);
+                                if (k < best[j]) {
+                                    best[j] = k;
+                                    w1[j] = b1; w2[j] = b2; w3[j] = b3;
+                                    slots = (slots & ~(0xFFu << (8 * j))) | ((uint32_t)r << (8 * j));
+                                    won |= 1u << j;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- the pixels this batch won: interpolate and store (.pyx:219, 226-242) ----------------------
+        if (mine_in && won) {
+            float *zp = elem(zb, pix0), *cp = elem(cb, (I)(pix0 * 3)), *np_ = elem(nb, (I)(pix0 * 3));
+            int32_t *wp = win ? reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix0)) : nullptr;
+            uint32_t prev = 0xFFFFFFFFu, tid_w = 0;
+            float cc[9], nn[9], z0 = 0.f, z1 = 0.f, z2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!((won >> j) & 1u) || Xs + XS * j >= X1) continue;
+                const uint32_t sl = (slots >> (8 * j)) & 0xFFu;
+                if (sl != prev) {            // (a thread's four pixels mostly share their winner)
+                    prev = sl;
+                    tid_w = oq.tri[sl];
+                    z0 = oq.z0[sl]; z1 = oq.z1[sl]; z2 = oq.z2[sl];
+                    const uint32_t at = L.pos_of ? L.pos_of[tid_w] : tid_w;
+                    load9(elem(col, (I)((I)at * 9)), cc);
+                    load9(elem(nrm, (I)((I)at * 9)), nn);
+                }
+                const float b1 = w1[j], b2 = w2[j], b3 = w3[j];
+                const float zv = interp(z0, z1, z2, b1, b2, b3);
+                float c0 = interp(cc[0], cc[3], cc[6], b1, b2, b3);
+                float c1 = interp(cc[1], cc[4], cc[7], b1, b2, b3);
+                float c2 = interp(cc[2], cc[5], cc[8], b1, b2, b3);
+                const float n0 = interp(nn[0], nn[3], nn[6], b1, b2, b3);
+                const float n1 = interp(nn[1], nn[4], nn[7], b1, b2, b3);
+                const float n2 = interp(nn[2], nn[5], nn[8], b1, b2, b3);
+                if (L.light.on) {
+                    const float f = guro_factor(L.light, n0, n1, n2);
+                    c0 *= f; c1 *= f; c2 *= f;
+                }
+                const int o = XS * j;
+                zp[o] = zv;
+                cp[3 * o] = c0; cp[3 * o + 1] = c1; cp[3 * o + 2] = c2;
+                np_[3 * o] = n0; np_[3 * o + 1] = n1; np_[3 * o + 2] = n2;
+                if (wp) wp[o] = (int32_t)tid_w;
+            }
+        }
+    }
+    // ---- background: the pixels no batch won (fused clear) ---------------------------------------------
+    if (CLEAR && mine_in) {
+        float *zp = elem(zb, pix0), *cp = elem(cb, (I)(pix0 * 3)), *np_ = elem(nb, (I)(pix0 * 3));
+        int32_t *wp = win ? reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix0)) : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (Xs + XS * j >= X1 || (uint32_t)best[j] != KEY_LOW_PRIOR) continue;
+            const int o = XS * j;
+            zp[o] = 1e6f;
+            cp[3 * o] = 0.0f; cp[3 * o + 1] = 0.0f; cp[3 * o + 2] = 0.0f;
+            np_[3 * o] = 0.0f; np_[3 * o + 1] = 0.0f; np_[3 * o + 2] = 0.0f;
+            if (wp) wp[o] = -1;
+        }
+    }
+    CR_STAMP(3);
+}
+
+// ---- the small records' kernel (kPathSmall): every batch goes through the run-wise sweep, over ROW SPANS ----
+// A triangle fills at most half of its pixel box (the 10 M small triangles: 5.1 of 16.8 box samples, T-Rex
+// 1024^2: 0.32 M of 0.96 M), and a wavefront cannot branch around the other samples' divisions: some lane
+// always has a sample inside.  So the samples are cut down BEFORE they become work items: the record's thread
+// works out, per row of the clipped box, the span [xa, xe] outside of which every sample is SURELY OUTSIDE
+// (raster_math.h (1)) — exactly:
+//   * edge k's numerator at row Y is n_k(X) = A_k - l_k2 * (X - xb_k), A_k = l_k1 * (Y - ya_k), every step one
+//     rounded float operation, each monotone: t_k(X) = n_k(X) * rej_k never increases with X when l_k2 * rej_k
+//     > 0 (the edge cuts the row on the RIGHT), never decreases when l_k2 * rej_k < 0 (on the LEFT);
+//   * the cut itself is guessed in real arithmetic (X = xb_k + A_k / l_k2, one fma with an approximate
+//     reciprocal; 1/32 of a pixel is given away), and then PROVEN on the first sample left out on either
+//     side with the very operations of numerators(): t_k < -2^-60 there for an edge that cuts on that side
+//     means the same for every sample further out.  A guess that cannot be proven gives that side of the
+//     row back whole (the box edge); a NaN proves nothing.  No overflow, hence no NaN that a monotone chain
+//     could hide, because records with a coordinate beyond 2^28 are not coded at all.
+// A coded record (box up to 16 x 16) carries, per row from its first row with samples, one byte (start,
+// end offsets) in four words and a mask of the rows that have any; its items are pairs of x-neighbours of
+// the SPANS.  Other records keep their box rows as spans.  The walk (sweep_runs32's, flat, stepped with
+// selects) takes a row's span from the record's words and steps over empty rows with the mask.
+struct SmallQueue {
+    float x0[kThreads], y0[kThreads], z0[kThreads];
+    float x1[kThreads], y1[kThreads], z1[kThreads];
+    float x2[kThreads], y2[kThreads], z2[kThreads];
+    uint32_t tri[kThreads];
+    uint32_t box[kThreads];          // small_box(): x0 | y0 << 5 | w << 10 | h << 16 | coded << 22 | skip << 26
+    float l03[kThreads], l13[kThreads], l23[kThreads];
+    float r1[kThreads], r2[kThreads], r3[kThreads];      // (r1 = 0: denominators outside the division window)
+    uint32_t px_scan[kThreads];      // exclusive prefix of the records' item counts within the wavefront
+    uint32_t rowmask[kThreads];      // rows (from the box's y0) that have samples
+    uint32_t span[4][kThreads];      // coded records: byte i = (start | end << 4) of row i, relative to the box's x0
+    uint32_t wave_px[kThreads / 64];
+};
+constexpr uint32_t kSmallCoded = 1u << 22;
+CR_DEV uint32_t small_box(int x0, int y0, int w, int h, bool coded)
+{
+    return (uint32_t)x0 | ((uint32_t)y0 << 5) | ((uint32_t)w << 10) | ((uint32_t)h << 16) | (coded ? kSmallCoded : 0u);
+}
+CR_DEV int small_x0(uint32_t b) { return (int)(b & 31u); }
+CR_DEV int small_y0(uint32_t b) { return (int)((b >> 5) & 31u); }
+CR_DEV int small_w(uint32_t b) { return (int)((b >> 10) & 63u); }
+
+// The spans of one record (its thread): clipped box [bx0, bx0 + bw) x [by0, by0 + bh), bw, bh <= 16.
+// Returns the item count; by0 moves down to the first row with samples (row 0 of the words and the mask).
+CR_DEV uint32_t row_spans(const TriSetup &s, int bx0, int &by0, int bw, int bh, uint32_t (&span)[4], uint32_t &rowmask)
+{
+    constexpr float kBias = 0.03125f, kBig = 1e30f;
+    // per edge: does it cut rows on the left or on the right, and the constants of the two guesses
+    const float l1[3] = {s.l01, s.l11, s.l21}, l2[3] = {s.l02, s.l12, s.l22};
+    const float ya[3] = {s.y2, s.y0, s.y1}, xb[3] = {s.x2, s.x0, s.x1};
+    const float rej[3] = {s.rej1, s.rej2, s.rej3};
+    float invL[3], xbL[3], invR[3], xbR[3], rejL[3], rejR[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float m = l2[k] * rej[k];
+        const bool isL = m < 0.0f, isR = m > 0.0f;
+        const float inv = __builtin_amdgcn_rcpf(l2[k]);
+        invL[k] = isL ? inv : 0.0f; xbL[k] = isL ? xb[k] - kBias : -kBig; rejL[k] = isL ? rej[k] : 0.0f;
+        invR[k] = isR ? inv : 0.0f; xbR[k] = isR ? xb[k] + kBias : kBig;  rejR[k] = isR ? rej[k] : 0.0f;
+    }
+    const float lo = (float)bx0, hi = (float)(bx0 + bw - 1);
+    uint32_t items = 0;
+    int first = -1;
+    span[0] = span[1] = span[2] = span[3] = 0u;
+    rowmask = 0u;
+    for (int r = 0; r < bh; ++r) {
+        const float fy = (float)(by0 + r);
+        float A[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) A[k] = l1[k] * (fy - ya[k]);          // numerators(): the row's share
+        float fa = lo, fe = hi;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            fa = fmaxf(fa, ceilf(__builtin_fmaf(A[k], invL[k], xbL[k])));
+            fe = fminf(fe, floorf(__builtin_fmaf(A[k], invR[k], xbR[k])));
+        }
+        fa = fminf(fa, hi + 1.0f);
+        fe = fmaxf(fe, lo - 1.0f);
+        // the proof: the first sample left out on either side, with numerators()'s own operations
+        bool okL = fa <= lo, okR = fe >= hi;
+        const float fxl = fa - 1.0f, fxr = fe + 1.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float tl = (A[k] - l2[k] * (fxl - xb[k])) * rejL[k];
+            const float tr = (A[k] - l2[k] * (fxr - xb[k])) * rejR[k];
+            okL = okL || tl < -kRejTiny;
+            okR = okR || tr < -kRejTiny;
+        }
+        fa = okL ? fa : lo;
+        fe = okR ? fe : hi;
+        const int xa = (int)fa - bx0, xe = (int)fe - bx0;                  // 0 .. bw, -1 .. bw - 1
+        if (xa <= xe) {
+            if (first < 0) first = r;
+            const int row = r - first;
+            span[row >> 2] |= ((uint32_t)xa | ((uint32_t)xe << 4)) << ((row & 3) * 8);
+            rowmask |= 1u << row;
+            items += (uint32_t)(xe - xa + 2) >> 1;
+        }
+    }
+    if (first > 0) by0 += first;
+    return items;
+}
+
+// Row `dy` of a record: its span in box-relative columns (uncoded records: the box row).
+CR_DEV void span_of(const SmallQueue &q, int r, uint32_t pb, int dy, int &xs, int &xe)
+{
+    const uint32_t byte = (q.span[(dy >> 2) & 3][r] >> ((dy & 3) * 8)) & 0xFFu;
+    const bool coded = (pb & kSmallCoded) != 0;
+    xs = coded ? (int)(byte & 15u) : 0;
+    xe = coded ? (int)(byte >> 4) : small_w(pb) - 1;
+}
+
+CR_DEV void sweep_spans32(const Tile<32> &c, const uint32_t *wo_, int total_)
+{
+    constexpr int TS = 32;
+    CR_TILE_LOCALS(c);
+    const SmallQueue &sq = *reinterpret_cast<const SmallQueue *>(qraw);
+    const int chunk = (total_ + kThreads - 1) / kThreads;
+    const int e = tid * chunk;
+    int left = (e + chunk < total_ ? e + chunk : total_) - e;       // items of this thread's run
+    if (left <= 0) return;
+    uint32_t i;
+    int r = find_record(sq.px_scan, wo_, e, i);
+    int dy = 0, px = 0;      // the item within its record: row (from the record's first), offset into the row's span
+    {
+        const uint32_t pb = sq.box[r], rm = sq.rowmask[r];
+        for (;;) {           // (i < the record's item count: the walk ends on a row with samples)
+            int xs, xe;
+            span_of(sq, r, pb, dy, xs, xe);
+            const uint32_t n = (uint32_t)(xe - xs + 2) >> 1;
+            if (i < n) break;
+            i -= n;
+            const uint32_t m = dy >= 31 ? 0u : rm >> (dy + 1);
+            if (m == 0u) { i = 0; break; }                          // (cannot happen; never walk off the record)
+            dy += __ffs((int)m);
+        }
+        px = (int)i * 2;
+    }
+    while (left > 0) {
+        const uint32_t pb = sq.box[r], rm = sq.rowmask[r];
+        int xs, xe;
+        span_of(sq, r, pb, dy, xs, xe);
+        const bool has = small_w(pb) != 0;
+        xe = has ? xe : -1;
+        const TriXYZ t{sq.x0[r], sq.y0[r], sq.z0[r], sq.x1[r], sq.y1[r], sq.z1[r], sq.x2[r], sq.y2[r], sq.z2[r]};
+        const uint32_t id = sq.tri[r];
+        TriSetup st;
+        {
+            st.x0 = t.x0; st.y0 = t.y0; st.z0 = t.z0; st.x1 = t.x1; st.y1 = t.y1; st.z1 = t.z1;
+            st.x2 = t.x2; st.y2 = t.y2; st.z2 = t.z2;
+            st.l01 = t.x1 - t.x2; st.l02 = t.y1 - t.y2;
+            st.l11 = t.x2 - t.x0; st.l12 = t.y2 - t.y0;
+            st.l21 = t.x0 - t.x1; st.l22 = t.y0 - t.y1;
+            st.l03 = sq.l03[r]; st.l13 = sq.l13[r]; st.l23 = sq.l23[r];
+            st.r1 = sq.r1[r]; st.r2 = sq.r2[r]; st.r3 = sq.r3[r];
+            st.fast = st.r1 != 0.0f;
+            st.rej1 = st.rej2 = st.rej3 = 0.0f;
+        }
+        const int lx = small_x0(pb) + xs + px, ly = small_y0(pb) + dy;       // tile-local
+        const int x = X0 + lx, y = Y0 + ly;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float n1, n2, n3;
+            numerators(st, x + j, y, n1, n2, n3);
+            unsigned long long k;
+            if (fragment_from(st, id, n1, n2, n3, true, k) && xs + px + j <= xe)
+                lds_key_min(&key[key_slot<TS>((lx + j) & 31, ly & 31)], k);
+        }
+        left -= has ? 1 : 0;
+        px += 2;
+        const bool row_done = xs + px > xe;
+        const uint32_t m = dy >= 31 ? 0u : rm >> (dy + 1);
+        const bool rec_done = row_done && m == 0u;
+        px = row_done ? 0 : px;
+        dy = rec_done ? 0 : row_done ? dy + __ffs((int)m) : dy;
+        r += rec_done ? 1 + (int)packed_skip(pb) : 0;
+    }
+}
+
+// The batch loop of the small records' kernel: queue (with the spans), key plane, sweep; the caller resolves.
+template <bool CLEAR>
+CR_DEV void small_batches(const Tile<32> &c, bool keys_early)
+{
+    constexpr int TS = 32;
+    CR_TILE_LOCALS(c);
+    SmallQueue &sq = *reinterpret_cast<SmallQueue *>(qraw);
+    uint32_t cur_id = 0, cur_bx = 0, cur_by = 0;
+    TriXYZ cur_t{};
+    bool cur_ok = beg + tid < end;
+    if (cur_ok) cur_ok = load_record(L, proj, G, beg + tid, cur_id, cur_t, cur_bx, cur_by);
+    CR_STAMP(1);
+    for (uint32_t base = beg; base < end; base += kThreads) {
+        int xl = 0, yt = 0, bw = 0, bh = 0;          // the record's box clipped to the rectangle
+        if (cur_ok) {
+            xl = (int)(cur_bx & 0xFFFF);
+            int xr = (int)(cur_bx >> 16);
+            yt = (int)(cur_by & 0xFFFF);
+            int yb = (int)(cur_by >> 16);
+            if (xl < X0) xl = X0;
+            if (xr > X1) xr = X1;
+            if (yt < Y0) yt = Y0;
+            if (yb > Y1) yb = Y1;
+            if (xl < xr && yt < yb) {
+                bw = xr - xl; bh = yb - yt;
+                // (a large triangle's box names tiles the triangle never touches: raster_body's test)
+                if (bw * bh >= 256 && rect_surely_missed(make_setup(cur_t, false), xl, xr - 1, yt, yb - 1)) bw = bh = 0;
+            }
+        }
+#ifdef CRENDER_STAMPS
+        if (base == beg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CR_STAMP(5); }
+#endif
+        const uint32_t blocks = (uint32_t)(((bw + 3) >> 2) * ((bh + 3) >> 2));
+        if (base == beg && wave == 0) {      // the tile's size class (TileLists::stats)
+            const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_sum(blocks), 63);
+            const uint32_t n0 = end - beg < 64u ? end - beg : 64u;
+            if (lane == 0) count_tile_class(L, tot0 >= 16u * n0);
+        }
+        uint32_t items = 0, rowmask = 0, span[4] = {0u, 0u, 0u, 0u};
+        bool coded = false;
+        TriSetup mine{};
+        if (bw != 0) {
+            mine = make_setup(cur_t, true);
+            const float big = fmaxf(fmaxf(fmaxf(fabsf(cur_t.x0), fabsf(cur_t.y0)), fmaxf(fabsf(cur_t.x1), fabsf(cur_t.y1))),
+                                    fmaxf(fabsf(cur_t.x2), fabsf(cur_t.y2)));
+#ifndef CRENDER_NO_SPANS
+            coded = bw <= 16 && bh <= 16 && big <= 268435456.0f;      // (false for a NaN coordinate)
+#endif
+            if (coded) {
+                const int y_was = yt;
+                items = row_spans(mine, xl, yt, bw, bh, span, rowmask);
+                bh -= yt - y_was;
+                if (items == 0) bw = bh = 0;        // every sample of the box surely outside
+            } else {
+                rowmask = bh >= 32 ? 0xFFFFFFFFu : (1u << bh) - 1u;
+                items = (uint32_t)(((bw + 1) >> 1) * bh);
+            }
+        }
+        const uint32_t incl_px = wave_incl_sum(items);
+        // previous batch's sweeps must be over before the queue is overwritten
+        if (base != beg) __syncthreads();
+        sq.x0[tid] = cur_t.x0; sq.y0[tid] = cur_t.y0; sq.z0[tid] = cur_t.z0;
+        sq.x1[tid] = cur_t.x1; sq.y1[tid] = cur_t.y1; sq.z1[tid] = cur_t.z1;
+        sq.x2[tid] = cur_t.x2; sq.y2[tid] = cur_t.y2; sq.z2[tid] = cur_t.z2;
+        sq.tri[tid] = cur_id;
+        {
+            const unsigned long long live = __builtin_amdgcn_ballot_w64(bw != 0);
+            const unsigned long long after = lane == 63 ? 0ull : live >> (lane + 1);
+            const uint32_t skip = after ? (uint32_t)__builtin_ctzll(after) : (uint32_t)(63 - lane);
+            sq.box[tid] = (bw != 0 ? small_box(xl - X0, yt - Y0, bw, bh, coded) : 0u) | (skip << 26);
+        }
+        if (bw != 0) {
+            sq.l03[tid] = mine.l03; sq.l13[tid] = mine.l13; sq.l23[tid] = mine.l23;
+            sq.r1[tid] = mine.fast ? mine.r1 : 0.0f; sq.r2[tid] = mine.r2; sq.r3[tid] = mine.r3;
+        }
+        sq.px_scan[tid] = incl_px - items;
+        sq.rowmask[tid] = bw != 0 ? rowmask : 0u;
+        sq.span[0][tid] = span[0]; sq.span[1][tid] = span[1]; sq.span[2][tid] = span[2]; sq.span[3][tid] = span[3];
+        if (lane == 63) sq.wave_px[wave] = incl_px;
+        __syncthreads();  // queue complete
+#ifdef CRENDER_STAMPS
+        if (base == beg) CR_STAMP(6);
+#endif
+        uint32_t wop[kThreads / 64 + 1];
+        wop[0] = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) wop[w + 1] = wop[w] + sq.wave_px[w];
+        const int total = (int)wop[kThreads / 64];
+        // next batch: issue its loads now, they complete under the sweep
+        const uint32_t nxt = base + kThreads + tid;
+        cur_ok = nxt < end;
+        if (cur_ok) cur_ok = load_record(L, proj, G, nxt, cur_id, cur_t, cur_bx, cur_by);
+        if (base == beg && !keys_early) {
+            init_keys<TS, CLEAR>(c);
+            __syncthreads();
+        }
+#ifdef CRENDER_STAMPS
+        if (g_stamps && base == beg && tid == 0) g_stamps[stamp_base + 12] = (unsigned long long)total;
+        if (base == beg) CR_STAMP(14);
+#endif
+        sweep_spans32(c, wop, total);
+#ifdef CRENDER_STAMPS
+        if (base == beg) CR_STAMP(15);
+#endif
+    }
 }
 
 // 64-pixel tiles, small records: each of the 16 lane groups takes one contiguous run of blocks,
@@ -1314,7 +1854,7 @@ CR_DEV void walk64_dense(const Tile<64> &c, const uint32_t *wo, int total)
     }
 }
 
-template <int TS, bool CLEAR>
+template <int TS, bool CLEAR, size_t QBYTES = raster_queue_bytes<TS>()>
 CR_DEV void resolve_tile(const Tile<TS> &c, bool slotted)
 {
     constexpr int kBatch = TS == 16 ? kBatch16 : kThreads;
@@ -1329,8 +1869,8 @@ CR_DEV void resolve_tile(const Tile<TS> &c, bool slotted)
     // whose entries (positions, a contiguous run) and their original indices (orig_of, near-contiguous)
     // the sweep has just read: they go into a hash table in the batch queue's LDS, free now, and the
     // pixels look their winners up there.  Lists too long for the table keep the global look-up.
-    constexpr uint32_t kHashSlots = (raster_queue_bytes<TS>() / sizeof(uint2)) >= 2048 ? 2048u : 1024u;
-    static_assert(kHashSlots * sizeof(uint2) <= raster_queue_bytes<TS>(), "the table takes the batch queue's place");
+    constexpr uint32_t kHashSlots = (QBYTES / sizeof(uint2)) >= 2048 ? 2048u : 1024u;
+    static_assert(kHashSlots * sizeof(uint2) <= QBYTES, "the table takes the batch queue's place");
     uint2 *hash_tab = reinterpret_cast<uint2 *>(qraw);
     const bool hashed = L.pos_of && L.pairs && end - beg <= kHashSlots / 2 && !(dbg & (1 << 21));
     auto hash_of = [](uint32_t orig) { return (orig * 2654435761u) >> (kHashSlots == 2048u ? 21 : 22); };
@@ -1407,7 +1947,7 @@ CR_DEV void resolve_tile(const Tile<TS> &c, bool slotted)
 // Workgroup `b` of a raster launch (the kernels below hand in their LDS: k_frame runs binning
 // wavefronts of another frame in the same launch): picks its tile, queues the tile's list batch by
 // batch and hands each batch to the sweep that suits it, then resolves the pixels.
-template <int TS, bool CLEAR>
+template <int TS, bool CLEAR, int PATH = kPathGeneral>
 CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict__ col,
                         const float *__restrict__ nrm, const TileLists &L,
                         float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
@@ -1477,7 +2017,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     // owners', they take the plane for their per-record words behind the queue's barrier.  Not on the large
     // frames: there most tiles are empty or the owners' and never need a key plane (bunny 4096^2 +3 % with it).
     // (Composite frames start from the depth buffer: see the batch loop.)
-    const bool keys_early = TS == 32 && CLEAR && L.nhelp > 0;
+    const bool keys_early = PATH != kPathOwners && TS == 32 && CLEAR && L.nhelp > 0;
     if (keys_early) init_keys<TS, CLEAR>(c);
     int rw = TS;                 // width of this workgroup's rectangle in the key plane's terms
     if (quad >= 0) {
@@ -1504,6 +2044,31 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
         // nothing to rasterize here: the rectangle keeps its content, or (fused clear) becomes
         // background — no key plane, no barriers
         if (CLEAR && X0 < X1 && Y0 < Y1) clear_rect<TS>(zb, cb, nb, win, G.W, X0, Y0, X1, Y1, L.vec_clear && quad < 0, tid);
+        CR_STAMP(3);
+    } else if constexpr (PATH == kPathOwners) {
+        c.X0 = X0; c.Y0 = Y0; c.X1 = X1; c.Y1 = Y1; c.rw = rw; c.quad = quad; c.beg = beg; c.end = end;
+        CR_STAMP(1);
+        if (end - beg <= (uint32_t)kThreads) {
+            owners_queue(c, beg, true);
+            CR_STAMP(6);
+            const OwnerQueue &oq = *reinterpret_cast<const OwnerQueue *>(qraw);
+            const float *pre = reinterpret_cast<const float *>(key);
+            if (L.addr32)
+                owner_tile<CLEAR, uint32_t, OwnerQueue>(oq, pre, (int)(end - beg), col, nrm, L.pos_of, L.light, zb, cb, nb, win,
+                                                        G.W, X0, Y0, X1, Y1);
+            else
+                owner_tile<CLEAR, size_t, OwnerQueue>(oq, pre, (int)(end - beg), col, nrm, L.pos_of, L.light, zb, cb, nb, win,
+                                                      G.W, X0, Y0, X1, Y1);
+            CR_STAMP(3);
+        } else {
+            owners_batches<CLEAR, size_t>(c);
+        }
+    } else if constexpr (PATH == kPathSmall) {
+        c.X0 = X0; c.Y0 = Y0; c.X1 = X1; c.Y1 = Y1; c.rw = rw; c.quad = quad; c.beg = beg; c.end = end;
+        small_batches<CLEAR>(c, keys_early);
+        __syncthreads();
+        CR_STAMP(2);
+        resolve_tile<TS, CLEAR, sizeof(SmallQueue)>(c, false);
         CR_STAMP(3);
     } else {
     // 16-pixel tiles with direct bins (at most 65536 triangles): a depth key's low word carries
@@ -1575,6 +2140,14 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
         const uint32_t my_blocks = per_pixel ? (uint32_t)(((box_w(box_wh) + kItemPixels - 1) / kItemPixels) * box_h(box_wh))
                                              : (uint32_t)blocks_of(box_wh);
         const uint32_t incl = wave_incl_sum(my_blocks);
+        if constexpr (TS == 32) {
+            // the tile's size class for the next frames' choice of kernel: the first wavefront's records
+            if (base == beg && wave == 0) {
+                const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t n0 = end - beg < 64u ? end - beg : 64u;
+                if (lane == 0) count_tile_class(L, tot0 >= 16u * n0);
+            }
+        }
         uint32_t incl_px = my_px;
         if constexpr (either) incl_px = wave_incl_sum(my_px);
         // previous batch's sweeps must be over before the queue is overwritten (the first batch has
@@ -1713,16 +2286,28 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     }
 }
 
-template <int TS, bool CLEAR>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? kWavesPerSimd16 : TS == 32 ? kWavesPerSimd32 : 1)))
+// LDS and wavefronts per SIMD of a kernel by tile size and path (see kPath*)
+template <int TS, int PATH>
+constexpr size_t path_queue_bytes()
+{
+    return PATH == kPathOwners ? sizeof(OwnerQueue) : PATH == kPathSmall ? sizeof(SmallQueue) : raster_queue_bytes<TS>();
+}
+template <int TS, int PATH>
+constexpr int path_waves()
+{
+    return TS == 16 ? kWavesPerSimd16 : TS != 32 ? 1 : PATH == kPathOwners ? kWavesPerSimdOwners : PATH == kPathSmall ? kWavesPerSimdSmall : kWavesPerSimd32;
+}
+template <int TS, bool CLEAR, int PATH = kPathGeneral>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(path_waves<TS, PATH>())))
 void k_raster(const float *__restrict__ proj, const float *__restrict__ col,
               const float *__restrict__ nrm, TileLists L,
               float *__restrict__ zb, float *__restrict__ cb, float *__restrict__ nb,
               int32_t *__restrict__ win, Geom G, int dbg_arg)
 {
-    __shared__ __attribute__((aligned(16))) unsigned long long key[TS * TS];   // (the pixel owners read it as float4)
-    __shared__ __attribute__((aligned(16))) unsigned char qraw[raster_queue_bytes<TS>()];
-    raster_body<TS, CLEAR>(proj, col, nrm, L, zb, cb, nb, win, G, dbg_arg, (int)blockIdx.x, key, qraw);
+    // (the pixel owners read the plane as float4: their eight words per record — the whole of it in kPathOwners)
+    __shared__ __attribute__((aligned(16))) unsigned long long key[TS * TS];
+    __shared__ __attribute__((aligned(16))) unsigned char qraw[path_queue_bytes<TS, PATH>()];
+    raster_body<TS, CLEAR, PATH>(proj, col, nrm, L, zb, cb, nb, win, G, dbg_arg, (int)blockIdx.x, key, qraw);
 }
 
 // One launch per frame for a stream of frames (crender_pipeline_*, direct bins): the raster pass of
@@ -1739,27 +2324,29 @@ struct RasterArgs {
     Geom G;
     int dbg;
 };
-static_assert(kSetupWaveLds <= raster_queue_bytes<16>() && kSetupWaveLds <= raster_queue_bytes<32>(),
+static_assert(kSetupWaveLds <= raster_queue_bytes<16>() && kSetupWaveLds <= raster_queue_bytes<32>() &&
+              kSetupWaveLds <= sizeof(OwnerQueue) && kSetupWaveLds <= sizeof(SmallQueue),
               "a binning wavefront works in the raster workgroup's batch queue");
+static_assert(sizeof(OwnerQueue) >= 128 + kOrderMaxTiles, "build_order keeps a byte per tile in the queue");
 struct FrameArgs {
     RasterArgs R;
     SetupArgs S;
     int nsetup;
 };
-template <int TS, bool CLEAR>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(TS == 16 ? kWavesPerSimd16 : TS == 32 ? kWavesPerSimd32 : 1)))
+template <int TS, bool CLEAR, int PATH = kPathGeneral>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(path_waves<TS, PATH>())))
 void k_frame(FrameArgs A)
 {
     __shared__ __attribute__((aligned(16))) unsigned long long key[TS * TS];   // (the pixel owners read it as float4)
-    __shared__ __attribute__((aligned(16))) unsigned char qraw[raster_queue_bytes<TS>()];
+    __shared__ __attribute__((aligned(16))) unsigned char qraw[path_queue_bytes<TS, PATH>()];
     if ((int)blockIdx.x < A.nsetup) {
         if (threadIdx.x < kWave)
             setup_wave_body<TS, true>(A.S.tri_in, A.S.nrm, A.S.proj_out, A.S.count, A.S.bins, A.S.dcap, A.S.hdr,
                                       A.S.hv, A.S.T, A.S.P, A.S.G, (int64_t)blockIdx.x, qraw);
         return;
     }
-    raster_body<TS, CLEAR>(A.R.proj, A.R.col, A.R.nrm, A.R.L, A.R.zb, A.R.cb, A.R.nb, A.R.win, A.R.G, A.R.dbg,
-                           (int)blockIdx.x - A.nsetup, key, qraw);
+    raster_body<TS, CLEAR, PATH>(A.R.proj, A.R.col, A.R.nrm, A.R.L, A.R.zb, A.R.cb, A.R.nb, A.R.win, A.R.G, A.R.dbg,
+                                 (int)blockIdx.x - A.nsetup, key, qraw);
 }
 
 // ---- second implementation: global 64-bit atomics ---------------------------------
@@ -1844,6 +2431,24 @@ __global__ __launch_bounds__(kThreads) void k_divcheck(const float *__restrict__
     }
 }
 
+// The size classes the plan's tiles reported last (TileLists::stats) -> the kernel its next frames get.
+// Reads the plan's own pinned records, newest first: the record of launch t carries the sums of launch
+// t - 1 (0, 0 for a plan's first launch and for other tile sizes: no opinion).  Three quarters of the covered
+// tiles one way make a frame that kernel's; anything else keeps the general one.
+void raster_path_hint(crender_plan *plan)
+{
+    for (uint64_t back = 0; back < 2 && back < plan->ticket; ++back) {
+        const uint64_t t = plan->ticket - back;
+        const volatile uint32_t *rec = plan->usage + kUsageWords * (int)(t % kUsageRing);
+        const uint32_t seq = (uint32_t)t ^ plan->usage_salt;
+        if (__atomic_load_n(const_cast<const uint32_t *>(rec), __ATOMIC_ACQUIRE) != seq || rec[7] != seq) continue;
+        const uint32_t nl = rec[4], ns = rec[5];
+        if (nl + ns == 0) return;
+        plan->auto_path = nl >= 3u * ns ? kPathOwners : ns >= 3u * nl ? kPathSmall : kPathGeneral;
+        return;
+    }
+}
+
 template <int TS>
 int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, const float *d_nrm,
                     float *d_z, float *d_color, float *d_normal, int32_t *d_winner, unsigned flags,
@@ -1892,39 +2497,69 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     const uintptr_t any = (uintptr_t)d_z | (uintptr_t)d_color | (uintptr_t)d_normal | (uintptr_t)d_winner;
     tl.vec_clear = (any & 15u) == 0 && (G.W & 3) == 0;
     tl.light = Light{plan->light[0], plan->light[1], plan->light[2], (flags & CRENDER_FUSED_GURO) ? 1 : 0};
+    // Which kernel (32-pixel plans; kPath*): the caller's choice (crender_plan_set_raster_path, or the
+    // process-wide default), else what the size classes of the plan's last reported frame suggest — a landed
+    // usage record of one of the two launches before this one carries them.  Every choice renders every
+    // tile exactly; a wrong one costs time.
+    int path = kPathGeneral;
+    if constexpr (TS == 32) {
+        raster_path_hint(plan);
+        path = plan->forced_path >= 0 ? plan->forced_path : default_raster_path() >= 0 ? default_raster_path() : plan->auto_path;
+    }
+    plan->last_path = path;
     // this launch's usage record (crender_plan_poll_bin_usage)
     plan->ticket++;
     const int uslot = (int)(plan->ticket % kUsageRing);
     plan->usage_mode[uslot] = direct ? 1 : pairbins ? 2 : 0;
     tl.hdr = plan->hdr();
-    tl.usage = plan->usage_dev + 4 * uslot;
+    tl.usage = plan->usage_dev + kUsageWords * uslot;
     tl.usage_seq = (uint32_t)plan->ticket ^ plan->usage_salt;
+    tl.stats = TS == 32 ? plan->stats((int)(plan->ticket & 1u)) : nullptr;
+    tl.stats_prev = TS == 32 ? plan->stats((int)((plan->ticket & 1u) ^ 1u)) : nullptr;
+    tl.path = (uint32_t)path;
     const unsigned grid = (unsigned)(G.ntiles + tl.nhelp + (ordered ? 1 : 0));
+    plan->awaiting[par ^ 1] = false;     // zeroed by this launch
+    plan->unrastered[par] = false;
+    const bool clear = (flags & CRENDER_FUSED_CLEAR) != 0;
+#define CR_LAUNCH_FRAME(P)                                                                                              \
+    do {                                                                                                                \
+        if (clear) hipLaunchKernelGGL((k_frame<TS, true, P>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, fa); \
+        else hipLaunchKernelGGL((k_frame<TS, false, P>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, fa);      \
+    } while (0)
+#define CR_LAUNCH_RASTER(P)                                                                                             \
+    do {                                                                                                                \
+        if (clear) hipLaunchKernelGGL((k_raster<TS, true, P>), dim3(grid), dim3(kThreads), 0, s, proj, d_col, d_nrm,    \
+                                      tl, d_z, d_color, d_normal, d_winner, G, dbg);                                    \
+        else hipLaunchKernelGGL((k_raster<TS, false, P>), dim3(grid), dim3(kThreads), 0, s, proj, d_col, d_nrm,         \
+                                tl, d_z, d_color, d_normal, d_winner, G, dbg);                                          \
+    } while (0)
     if constexpr (TS <= 32) {
         if (with_setup) {
             // this frame's raster pass and another plan's binning pass in one launch (k_frame)
             const int nsetup = (int)((with_setup->T + kWave - 1) / kWave);
             const RasterArgs ra{proj, d_col, d_nrm, tl, d_z, d_color, d_normal, d_winner, G, dbg};
             const FrameArgs fa{ra, *with_setup, nsetup};
-            if (flags & CRENDER_FUSED_CLEAR)
-                hipLaunchKernelGGL((k_frame<TS, true>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, fa);
-            else
-                hipLaunchKernelGGL((k_frame<TS, false>), dim3(grid + (unsigned)nsetup), dim3(kThreads), 0, s, fa);
+            if constexpr (TS == 32) {
+                if (path == kPathOwners) CR_LAUNCH_FRAME(kPathOwners);
+                else if (path == kPathSmall) CR_LAUNCH_FRAME(kPathSmall);
+                else CR_LAUNCH_FRAME(kPathGeneral);
+            } else {
+                CR_LAUNCH_FRAME(kPathGeneral);
+            }
             CR_LAUNCH_CHECK("k_frame");
-            plan->awaiting[par ^ 1] = false;
-            plan->unrastered[par] = false;
             return CRENDER_OK;
         }
     }
-    if (flags & CRENDER_FUSED_CLEAR)
-        hipLaunchKernelGGL((k_raster<TS, true>), dim3(grid), dim3(kThreads), 0, s, proj, d_col, d_nrm, tl,
-                           d_z, d_color, d_normal, d_winner, G, dbg);
-    else
-        hipLaunchKernelGGL((k_raster<TS, false>), dim3(grid), dim3(kThreads), 0, s, proj, d_col, d_nrm, tl,
-                           d_z, d_color, d_normal, d_winner, G, dbg);
+    if constexpr (TS == 32) {
+        if (path == kPathOwners) CR_LAUNCH_RASTER(kPathOwners);
+        else if (path == kPathSmall) CR_LAUNCH_RASTER(kPathSmall);
+        else CR_LAUNCH_RASTER(kPathGeneral);
+    } else {
+        CR_LAUNCH_RASTER(kPathGeneral);
+    }
+#undef CR_LAUNCH_FRAME
+#undef CR_LAUNCH_RASTER
     CR_LAUNCH_CHECK("k_raster");
-    plan->awaiting[par ^ 1] = false;     // zeroed by this launch
-    plan->unrastered[par] = false;
     return CRENDER_OK;
 }
 

@@ -105,6 +105,14 @@ class Plan:
         """0 = count / scan / fill, 1 = direct bins, 2 = pair bins."""
         return int(self._lib.crender_plan_last_frame_binning(self.handle))
 
+    def set_raster_path(self, path):
+        """-1 = the plan chooses (default), 0 = general kernel, 1 = pixel owners only, 2 = small records only;
+        every choice renders every tile exactly (crender_plan_set_raster_path)."""
+        _capi.check(self._lib.crender_plan_set_raster_path(self.handle, int(path)), "crender_plan_set_raster_path")
+
+    def last_raster_path(self):
+        return int(self._lib.crender_plan_last_raster_path(self.handle))
+
     def bin_usage(self):
         need, cap = C.c_int64(), C.c_int64()
         with torch.cuda.device(self.device):

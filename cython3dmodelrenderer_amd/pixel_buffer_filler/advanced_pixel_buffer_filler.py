@@ -153,6 +153,9 @@ class _FramePipeline:
                                                      filler.y1, max(int(T), 1), cap,
                                                      tile, ws.data_ptr(), nbytes, filler._stream()),
                         "crender_plan_create")
+            if filler._raster_path is not None:
+                _capi.check(self.lib.crender_plan_set_raster_path(plan, int(filler._raster_path)),
+                            "crender_plan_set_raster_path")
             self.plans.append(plan)
             self.workspaces.append(ws)
         self.max_T = max(int(T), 1)
@@ -260,7 +263,7 @@ class AdvancedPixelBufferFiller:
     def __init__(self, h, w, fov=90.0, z_near=0.1, z_far=1000.0, n_threads=1, *,
                  device=None, tile=0, row_strip=None, track_winner=False, cache_inputs=False,
                  bin_capacity=0, direct_bins=True, pipeline=False, pipeline_depth=None,
-                 presort=None, lookahead=None):
+                 presort=None, lookahead=None, raster_path=None):
         self._lib = _capi.load()                      # raises if the HIP library is missing
         self._ext = _torch_ext.load()                 # raises if the torch extension is not built
         if not torch.cuda.is_available():
@@ -321,6 +324,10 @@ class AdvancedPixelBufferFiller:
         # T-Rex 1024 x 1024: 9 % more frames per second than on the 16-pixel tiles a frame rendered
         # alone gets (a quarter of the workgroups).  (bench.py's A/B sets it.)
         self._pipeline_tile = None
+        # Which raster kernel the plans' frames get (crender_plan_set_raster_path): None = each plan chooses
+        # by the size classes its previous frames counted; 0 / 1 / 2 = general / pixel owners / small records.
+        # Speed only: every kernel renders every tile exactly.
+        self._raster_path = raster_path
         self._order = None             # (orig_of, pos_of) int32 device tensors of the resident inputs
         self._plan_order = None        # what the single-stream plan currently holds
         self._fused_light = None       # (l0, l1, l2): illumination fused into cleared frames
@@ -378,6 +385,9 @@ class AdvancedPixelBufferFiller:
                                                   max_T, int(capacity), self.tile,
                                                   self._workspace.data_ptr(), nbytes, self._stream()),
                     "crender_plan_create")
+        if self._raster_path is not None:
+            _capi.check(self._lib.crender_plan_set_raster_path(plan, int(self._raster_path)),
+                        "crender_plan_set_raster_path")
         self._plan = plan
         self._plan_max_T = max_T
         # a fresh plan has no triangle order and no light, whatever the address the allocator gave
@@ -387,6 +397,12 @@ class AdvancedPixelBufferFiller:
         _capi.check(self._lib.crender_plan_last_bin_usage(plan, self._stream(), C.byref(need),
                                                           C.byref(cap)), "crender_plan_last_bin_usage")
         self._plan_capacity = cap.value
+
+    def last_raster_paths(self):
+        """Which raster kernel the most recent launch of every live plan was (crender_plan_last_raster_path:
+        0 general, 1 pixel owners, 2 small records): the single-stream plan first, then the swap chain's."""
+        plans = ([self._plan] if self._plan else []) + (list(self._pipe.plans) if self._pipe is not None else [])
+        return [int(self._lib.crender_plan_last_raster_path(p)) for p in plans]
 
     def _chain_tile(self):
         """Tile size of the swap chain's plans: the caller's `tile` if one was given; else 32-pixel

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CRENDER_ABI_VERSION 5
+#define CRENDER_ABI_VERSION 6
 #define CRENDER_API __attribute__((visibility("default")))
 
 enum {
@@ -155,6 +155,12 @@ CRENDER_API int crender_plan_last_frame_binning(crender_plan *plan);
  *                                has not — nothing is waited for, nothing is enqueued; CRENDER_EINVAL
  *                                for a frame never launched or older than the last 8.
  * Once `stream` of that launch has been synchronised by any means the record is there. */
+/* CRENDER_OK means "this frame's binning figures are known" — the record is written when the raster launch
+ * STARTS its last workgroup (the binning pass ran in an earlier launch), not when the framebuffers are
+ * written: it is no completion signal.  A record is two aligned 16-byte stores with the frame's sequence
+ * word first and last; it is taken only when both are there.  On a swap chain with look-ahead the NEXT
+ * frame's binning wavefronts run inside this launch and raise the same sticky overflow word: an overflow
+ * of theirs may be reported one frame early (conservative: the frame is rendered again). */
 CRENDER_API uint64_t crender_plan_frame_ticket(crender_plan *plan);
 CRENDER_API int crender_plan_poll_bin_usage(crender_plan *plan, uint64_t ticket, int64_t *needed,
                                             int64_t *capacity);
@@ -185,6 +191,27 @@ CRENDER_API int crender_plan_set_triangle_order(crender_plan *plan, const uint32
  * sum and its comparison — still runs every frame, on the same values: results are unchanged.
  * Used by the scan path's binning pass (scenes beyond the direct bins). */
 CRENDER_API int crender_plan_set_normal_z(crender_plan *plan, const float *d_nz);
+
+/* Which raster kernel a plan's frames get (no reference counterpart: the reference has one loop nest,
+ * .pyx:196-244, and so has every kernel here — the choice is about speed only).  Plans on 32-pixel tiles
+ * have three kernels that all render EVERY tile exactly (the parity tests force each through every scene):
+ *   0  the general one, every sweep in it (6 wavefronts per SIMD);
+ *   1  the pixel owners alone — frames of large triangles (bunny 4096^2, T-Rex 8192^2): no key plane, 19.5 KB
+ *      of LDS, 7 wavefronts per SIMD;
+ *   2  the run-wise sweep over exact row spans alone — frames of small triangles (10 M-triangle soups,
+ *      T-Rex 1024^2 on a swap chain's 32-pixel plans): samples surely outside a triangle never become work.
+ * -1 (the default) lets the plan choose: every raster launch counts its covered tiles by the size of their
+ * records and leaves the counts in the launch's usage record (crender_plan_poll_bin_usage's pinned memory);
+ * the plan reads its own last landed record before a launch — no copy, no synchronisation — and takes 1 or
+ * 2 when three quarters of the tiles are of that kind, else 0.  The first frames of a plan get 0.
+ * Other tile sizes have the general kernel only and ignore the setting.
+ *   crender_plan_set_raster_path      fix the kernel of this plan's frames, or hand the choice back (-1)
+ *   crender_plan_last_raster_path     which kernel the most recent raster launch of the plan was
+ *   crender_set_default_raster_path   process-wide: what plans on -1 take instead of choosing (-1: choose);
+ *                                     the parity tests run the whole suite under each value */
+CRENDER_API int crender_plan_set_raster_path(crender_plan *plan, int path);
+CRENDER_API int crender_plan_last_raster_path(crender_plan *plan);
+CRENDER_API int crender_set_default_raster_path(int path);
 
 /* Light direction (host pointer to 3 floats, copied) for frames rendered with CRENDER_FUSED_GURO:
  * GuroIllumination.__init__'s light_direction (guro_illumination.py:6-18). */

@@ -186,12 +186,11 @@ def test_back_face_test_divides_in_double(oracle, tmp_path):
     """.pyx:202 culls on `(n0z + n1z + n2z) / 3 >= 0.0` with float operands and an int literal.  The
     oracle (and the HIP `backface`) take the division to be a DOUBLE one — then the test equals
     `sum >= 0` — which matters for exactly one input: a sum of -1.4e-45 (the smallest negative
-    denormal) divided by 3 in FLOAT would round to -0, and -0 >= 0 would cull the triangle.  No build
-    of the reference's filler exists here to decide it; what can be pinned is
-    what Cython emits for that very expression: this container's Cython, the one oracle/build_ref.sh
-    compiles the reference's math_utils.pyx with, turns a statement of the same shape (written here,
-    not the reference's text) into `... / 3.0) >= 0.0` — C's double division.  "Parity unpinned" for
-    any Cython that would emit something else."""
+    denormal) divided by 3 in FLOAT would round to -0, and -0 >= 0 would cull the triangle.
+    Pinned on the reference's OWN text: the filler's .pyx is cythonized to C here (code generation
+    only — nothing of it is compiled, imported or run, and nothing of it is stored: the C file lives
+    in the test's temporary directory) and the statement Cython emits for line 202 must divide by the
+    double literal `3.0`.  Build container only: the checkout never travels (skipped where absent)."""
     import re
     import shutil
     import subprocess
@@ -205,19 +204,20 @@ def test_back_face_test_divides_in_double(oracle, tmp_path):
         f = oracle.OracleFiller(64, 64, fov=45)
         f.render_arrays(tri, col, nrm)
         assert bool((f.z_buffer < 1e6).any()) == drawn, zs
-    # 2. what Cython emits for an expression of that shape
+    # 2. what Cython emits for the reference's line 202 itself
+    pyx = "/root/reference/crender/cy/pixel_buffer_filler/advanced_pixel_buffer_filler.pyx"
     cython = shutil.which("cython")
-    if cython is None:
-        pytest.skip("no cython here: the division's type stays unpinned")
-    (tmp_path / "snippet.pyx").write_text(
-        "# cython: language_level=3\n"
-        "cdef int faces_away(float[:, :, :] n, Py_ssize_t i) nogil:\n"
-        "    if (n[i, 0, 2] + n[i, 1, 2] + n[i, 2, 2]) / 3 >= 0.0:\n"
-        "        return 1\n"
-        "    return 0\n")
-    subprocess.check_call([cython, "snippet.pyx"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    c = (tmp_path / "snippet.c").read_text()
-    stmt = [l for l in c.splitlines() if ">= 0.0)" in l and "__pyx_v_n.data" in l]
-    assert len(stmt) == 1
-    assert re.search(r"\)\s*/\s*3\.0\)\s*>=\s*0\.0\)", stmt[0]), stmt[0][-80:]
-    assert "(float)3" not in stmt[0] and "3.0f" not in stmt[0]
+    if cython is None or not os.path.exists(pyx):
+        pytest.skip("no cython / no reference checkout here: the division's type is pinned in the build container")
+    out = tmp_path / "filler.c"
+    subprocess.check_call([cython, "-3", "-X", "legacy_implicit_noexcept=True", pyx, "-o", str(out)],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lines = out.read_text().splitlines()
+    # the C statement(s) generated under the source-line marker of .pyx:202
+    marks = [i for i, l in enumerate(lines) if 'advanced_pixel_buffer_filler.pyx":202' in l]
+    assert marks, "no code generated for .pyx:202"
+    stmt = [l for i in marks for l in lines[i:i + 80] if ">= 0.0)" in l and "__pyx_v_normals.data" in l]
+    assert stmt, "the cull test of .pyx:202 was not found in the generated C"
+    for l in stmt:
+        assert re.search(r"\)\s*/\s*3\.0\)\s*>=\s*0\.0\)", l), l[-80:]
+        assert "(float)3" not in l and "3.0f" not in l
