@@ -323,10 +323,10 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the next frame's bin pass with this frame's raster pass")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL all-gather")
-    ap.add_argument("--raster-path", default="auto", choices=["auto", "0", "1", "2"],
+    ap.add_argument("--raster-path", default="auto", choices=["auto", "0", "1"],
                     help="which raster kernel 32-pixel plans use: auto = each plan's own choice from the size classes "
-                         "its previous frames counted (the product's default), 0 general, 1 pixel owners only, "
-                         "2 small records only — every one exact on every tile (A/B knob)")
+                         "its previous frames counted (the product's default), 0 general, 1 pixel owners only — "
+                         "both exact on every tile (A/B knob)")
     ap.add_argument("--pipeline-depth", type=int, default=0,
                     help="frames in flight (swap-chain depth); 0 = the filler's choice")
     ap.add_argument("--lookahead", default="auto", choices=["auto", "on", "off"],
@@ -572,7 +572,7 @@ def main():
         single_ms = elapsed_single / args.steps * 1e3
         raster_b2b_ms = max(single_ms - bin_ms, 0.0)
         ts = (filler._pipe.tile if lookahead else filler.tile) or (16 if H * W <= 1024 * 1024 else 32)
-        # (32-pixel plans have three raster kernels, all exact; which one these launches were: the plans say)
+        # (32-pixel plans have two raster kernels, both exact; which one these launches were: the plans say)
         paths = filler.last_raster_paths()
         kpath = (probe_paths[-1] if lookahead else paths[0]) if ts == 32 else 0
         if lookahead:
@@ -611,7 +611,7 @@ def main():
                        "tile": filler.tile or "auto",
                        "pipeline_tile": filler._pipe.tile if filler._pipe is not None else None,
                        "raster_path": {"asked": args.raster_path, "last_launch_of_each_plan": paths,
-                                       "what": "0 general kernel, 1 pixel owners only, 2 small records (row spans) only; "
+                                       "what": "0 general kernel, 1 pixel owners only; "
                                                "auto: each plan picks by the tile size classes its previous frames counted"},
                        "frame": "clear + project + rasterize, model resident in HBM",
                        "pipelined": (False if args.no_pipeline else

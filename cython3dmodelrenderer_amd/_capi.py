@@ -11,14 +11,14 @@ import os
 from . import _build
 
 ABI_VERSION = 6
-OK, EINVAL, EHIP, ENOMEM, EBUSY = 0, 1, 2, 3, 4
+OK, EINVAL, EHIP, ENOMEM, EBUSY, ESTATE = 0, 1, 2, 3, 4, 5
 FUSED_CLEAR = 1
 NO_DIRECT_BINS = 2
 OVERLAPPED_FRAMES = 4
 FUSED_GURO = 8
 STATIC_INPUTS = 16
-# raster kernels of a 32-pixel plan (crender_plan_set_raster_path): all exact on every tile
-PATH_AUTO, PATH_GENERAL, PATH_OWNERS, PATH_SMALL = -1, 0, 1, 2
+# raster kernels of a 32-pixel plan (crender_plan_set_raster_path): both exact on every tile
+PATH_AUTO, PATH_GENERAL, PATH_OWNERS = -1, 0, 1
 
 _vp, _i32, _i64, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint, C.c_size_t
 _f32p = C.POINTER(C.c_float)
@@ -40,6 +40,7 @@ SIGNATURES = {
     "crender_plan_frame_ticket": (C.c_uint64, [_vp]),
     "crender_plan_poll_bin_usage": (_i32, [_vp, C.c_uint64, C.POINTER(_i64), C.POINTER(_i64)]),
     "crender_plan_set_light": (_i32, [_vp, _f32p]),
+    "crender_plan_debug_check": (_i32, [_vp, _vp, C.c_char_p, _sz]),
     "crender_plan_set_raster_path": (_i32, [_vp, _i32]),
     "crender_plan_last_raster_path": (_i32, [_vp]),
     "crender_set_default_raster_path": (_i32, [_i32]),
@@ -107,12 +108,12 @@ def load():
     got = L.crender_abi_version()
     if got != ABI_VERSION:
         raise CrenderError(f"libcrender_hip.so ABI {got}, binding expects {ABI_VERSION}")
-    # CRENDER_RASTER_PATH=0|1|2: every plan that has not been told otherwise renders with that kernel
+    # CRENDER_RASTER_PATH=0|1: every plan that has not been told otherwise renders with that kernel
     # (crender_set_default_raster_path) — how the parity suite is run once per kernel
     forced = os.environ.get("CRENDER_RASTER_PATH")
     if forced not in (None, ""):
         if L.crender_set_default_raster_path(int(forced)) != OK:
-            raise CrenderError(f"CRENDER_RASTER_PATH={forced}: expected -1, 0, 1 or 2")
+            raise CrenderError(f"CRENDER_RASTER_PATH={forced}: expected -1, 0 or 1")
     _lib = L
     return L
 
@@ -121,6 +122,16 @@ def check(status: int, what: str):
     if status != OK:
         msg = load().crender_last_error()
         raise CrenderError(f"{what} failed (code {status}): {msg.decode() if msg else ''}")
+
+
+def plan_debug_check(plan_handle, stream):
+    """crender_plan_debug_check: raises CrenderError with the findings if the plan's cross-frame state is
+    inconsistent (synchronises `stream`)."""
+    buf = C.create_string_buffer(2048)
+    rc = load().crender_plan_debug_check(plan_handle, stream, buf, len(buf))
+    if rc == ESTATE:
+        raise CrenderError("plan state: " + buf.value.decode(errors="replace"))
+    check(rc, "crender_plan_debug_check")
 
 
 def f32_16(mat):

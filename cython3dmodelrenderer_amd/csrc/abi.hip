@@ -384,6 +384,124 @@ int crender_plan_poll_bin_usage(crender_plan *plan, uint64_t ticket, int64_t *ne
     return CRENDER_OK;
 }
 
+// ---- state check between frames (diagnostics) ---------------------------------------------------------------
+// A plan carries state from frame to frame that no single frame's pixels show: two parities of per-tile
+// counters, the split tiles' flag and helper-slot words, the registration and hint_bad counters, the dispatch
+// order and its header, the ring of usage records.  Four defects of rounds 4-5 were words of that state left
+// behind by one frame and found, frames later, by their pixel symptom.  This reads the state back and checks
+// the invariants themselves.
+int crender_plan_debug_check(crender_plan *plan, void *stream, char *msg, size_t msg_bytes)
+{
+    if (!plan) return fail(CRENDER_EINVAL, "null plan");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Layout &L = plan->L;
+    const int nt = L.g.ntiles;
+    std::vector<unsigned char> host(L.off_offs);
+    CR_HIP(hipMemcpyAsync(host.data(), plan->ws, L.off_offs, hipMemcpyDeviceToHost, s));
+    CR_HIP(hipStreamSynchronize(s));
+    auto words = [&](size_t off) { return reinterpret_cast<const uint32_t *>(host.data() + off); };
+    const uint32_t *hdr = words(L.off_hdr), *hflag = words(L.off_hflag), *hslots = words(L.off_hslots);
+    const uint32_t *cnt[2] = {words(L.off_count), words(L.off_count) + L.count_stride};
+    std::string bad;
+    char line[256];
+    auto say = [&](const char *fmt, auto... a) {
+        if (bad.size() > 1500) return;
+        std::snprintf(line, sizeof line, fmt, a...);
+        bad += line;
+        bad += "; ";
+    };
+    const int par = plan->parity;
+    const bool binned_only = plan->unrastered[par];          // binned, its raster launch not issued yet
+    const bool virgin = plan->frame_no == 0;
+    if (!virgin && !plan->unrastered[0] && !plan->unrastered[1]) {
+        // (A) the last frame was rasterized: the other parity is ready for the next frame, nothing is handed off
+        int nz = 0, first = -1;
+        for (int i = 0; i < nt; ++i)
+            if (cnt[par ^ 1][i]) { if (first < 0) first = i; ++nz; }
+        if (nz) say("%d counters of parity %d (the NEXT frame's) are not zero, first tile %d = %u", nz, par ^ 1, first, cnt[par ^ 1][first]);
+        if (plan->awaiting[par ^ 1]) say("host flag awaiting[%d] still set after the raster launch", par ^ 1);
+        if (hdr[2 + (par ^ 1)]) say("registration counter of the next frame hdr[%d] = %u", 2 + (par ^ 1), hdr[2 + (par ^ 1)]);
+        if (hdr[5 + (par ^ 1)]) say("hint_bad of the next frame hdr[%d] = %u", 5 + (par ^ 1), hdr[5 + (par ^ 1)]);
+        int nf = 0, ff = -1;
+        for (int i = 0; i < nt; ++i)
+            if (hflag[i]) { if (ff < 0) ff = i; ++nf; }
+        if (nf) say("%d split flags left up after the raster launch, first tile %d", nf, ff);
+        int nsl = 0, fs = -1;
+        for (int i = 0; i < 3 * (L.hmax > 0 ? L.hmax : 1); ++i)
+            if (hslots[i]) { if (fs < 0) fs = i; ++nsl; }
+        if (nsl) say("%d helper-slot words left set after the raster launch, first slot %d = tile %u", nsl, fs, hslots[fs] - 1);
+    } else if (binned_only && !plan->unrastered[par ^ 1]) {
+        // (B) binned, not rasterized yet: the registrations must match the flags, the slots and the lists
+        const bool split = plan->last_frame_direct && L.hmax > 0 && plan->frame_lone;
+        const uint32_t at = heavy_at(L.ts);
+        if (split) {
+            const uint32_t reg = hdr[2 + par];
+            const uint32_t used = reg < (uint32_t)L.hmax ? reg : (uint32_t)L.hmax;
+            std::vector<int> slot_of(nt, -1);
+            for (uint32_t k = 0; k < (uint32_t)L.hmax; ++k) {
+                const uint32_t a = hslots[3 * k], b = hslots[3 * k + 1], c = hslots[3 * k + 2];
+                if (k >= used) {
+                    if (a | b | c) say("helper triple %u beyond the %u registered holds tiles %u %u %u", k, used, a, b, c);
+                    continue;
+                }
+                if (a == 0 || a != b || a != c || a > (uint32_t)nt) { say("helper triple %u of %u registered holds %u %u %u", k, used, a, b, c); continue; }
+                const int tile = (int)a - 1;
+                if (slot_of[tile] >= 0) say("tile %d registered twice (triples %d and %u)", tile, slot_of[tile], k);
+                slot_of[tile] = (int)k;
+                if (!hflag[tile]) say("tile %d has helper triple %u but no flag", tile, k);
+                if (cnt[par][tile] < at) say("tile %d registered with a list of %u < %u", tile, cnt[par][tile], at);
+            }
+            uint32_t nheavy = 0;
+            for (int i = 0; i < nt; ++i) {
+                if (cnt[par][i] >= at) ++nheavy;
+                if (hflag[i] && slot_of[i] < 0) say("tile %d flagged without a helper triple", i);
+            }
+            if (nheavy != reg) say("%u tiles reach %u entries but %u registered", nheavy, at, reg);
+        } else {
+            for (int i = 0; i < nt; ++i)
+                if (hflag[i]) { say("split flag of tile %d up on a frame that is not split", i); break; }
+        }
+    }
+    // the dispatch order the next ordered launch reads: a permutation, its grouped section as the header says
+    if (L.ordered && plan->last_ordered) {
+        const int hp = plan->hint_par;
+        const uint32_t *hint = words(L.off_hint) + 4 * hp;
+        const uint32_t *order = words(L.off_order) + (size_t)hp * nt;
+        const unsigned char *grouped = host.data() + L.off_grouped + (size_t)hp * nt;
+        std::vector<unsigned char> seen(nt, 0);
+        int dup = 0, oob = 0;
+        for (int i = 0; i < nt; ++i) {
+            if (order[i] >= (uint32_t)nt) { ++oob; continue; }
+            if (seen[order[i]]++) ++dup;
+        }
+        if (dup || oob) say("the dispatch order is no permutation (%d repeated, %d out of range)", dup, oob);
+        const uint32_t ns = hint[1];
+        if (ns > (uint32_t)nt) say("order header: %u tiles with a workgroup of their own of %d", ns, nt);
+        else if (!dup && !oob) {
+            int wrong = 0;
+            for (int i = 0; i < nt; ++i)
+                if ((grouped[order[i]] != 0) != ((uint32_t)i >= ns)) ++wrong;
+            if (wrong) say("%d tiles whose `grouped` byte disagrees with their place in the order", wrong);
+            const int g = L.ts >= 32 ? 2 : 8;
+            if (hint[2] != ((uint32_t)nt - ns + g - 1) / g) say("order header: %u groups for %u grouped tiles", hint[2], (uint32_t)nt - ns);
+        }
+    }
+    // the usage ring: every landed record is one of this plan's launches, in its own slot, whole
+    for (int k = 0; k < kUsageRing; ++k) {
+        const volatile uint32_t *rec = plan->usage + kUsageWords * k;
+        const uint32_t a = rec[0], z = rec[7];
+        if (a == 0 && z == 0) continue;
+        const uint64_t t = (uint64_t)(a ^ plan->usage_salt);
+        if (a != z) say("usage record %d: leading word %08x, trailing word %08x", k, a, z);
+        else if (t == 0 || t > plan->ticket || (int)(t % kUsageRing) != k) say("usage record %d names launch %llu of %llu", k, (unsigned long long)t, (unsigned long long)plan->ticket);
+    }
+    if (msg && msg_bytes) {
+        std::snprintf(msg, msg_bytes, "%s", bad.c_str());
+    }
+    if (!bad.empty()) return fail(CRENDER_ESTATE, "crender_plan_debug_check: the plan's cross-frame state is inconsistent (text in msg)");
+    return CRENDER_OK;
+}
+
 int crender_plan_set_triangle_order(crender_plan *plan, const uint32_t *d_orig_of, const uint32_t *d_pos_of)
 {
     if (!plan || ((d_orig_of == nullptr) != (d_pos_of == nullptr)))
@@ -409,7 +527,7 @@ int crender_plan_set_light(crender_plan *plan, const float *light3)
 
 int crender_plan_set_raster_path(crender_plan *plan, int path)
 {
-    if (!plan || path < -1 || path > 2) return fail(CRENDER_EINVAL, "crender_plan_set_raster_path: path is -1 (automatic), 0, 1 or 2");
+    if (!plan || path < -1 || path > 1) return fail(CRENDER_EINVAL, "crender_plan_set_raster_path: path is -1 (automatic), 0 or 1");
     plan->forced_path = path;
     return CRENDER_OK;
 }
@@ -418,7 +536,7 @@ int crender_plan_last_raster_path(crender_plan *plan) { return plan ? plan->last
 
 int crender_set_default_raster_path(int path)
 {
-    if (path < -1 || path > 2) return fail(CRENDER_EINVAL, "crender_set_default_raster_path: path is -1 (automatic), 0, 1 or 2");
+    if (path < -1 || path > 1) return fail(CRENDER_EINVAL, "crender_set_default_raster_path: path is -1 (automatic), 0 or 1");
     g_default_path.store(path, std::memory_order_relaxed);
     return CRENDER_OK;
 }
@@ -534,6 +652,11 @@ int crender_pipeline_frame(crender_pipeline *p, const float *d_tri, const float 
         p->synced = true;
     }
     const int k = (int)(p->n % (uint64_t)p->depth);
+    {   // the chain's plans share what any of them has learnt about the frames' size class (raster_path_hint)
+        crender_plan *use = (p->ahead[k] && P16 && T > 0 && p->sel[k]) ? p->ahead[k] : p->plan[k];
+        if (raster_path_hint(use)) { p->shared_path = use->auto_path; p->shared_known = true; }
+        else if (p->shared_known) { use->auto_path = p->shared_path; use->auto_known = true; }
+    }
     const bool timed = p->timing();
     if (timed) CR_HIP(hipEventRecord(p->events[(size_t)p->timed_frames * 2], p->s[k]));
     struct Stamp {      // the closing event, whichever way the frame leaves this function with success

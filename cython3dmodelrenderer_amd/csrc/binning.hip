@@ -591,7 +591,11 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
     const int par = (int)(plan->frame_no++ & 1u);
     plan->parity = par;
     plan->frame_lone = !(flags & CRENDER_OVERLAPPED_FRAMES) || (dbg & 16384);
+#if defined(CRENDER_FAULT) && CRENDER_FAULT == 2     // (round 5's defect back in, for the state check's own test: scripts/r6_faults.sh)
+    if (plan->awaiting[par]) {
+#else
     if (plan->awaiting[par] || plan->unrastered[par ^ 1]) {
+#endif
         // this parity was binned into and not zeroed since, or the other one was binned into and never
         // rasterized (the swap chain binned ahead for inputs that then changed; crender_prepare twice in a
         // row): start over from the state crender_plan_create leaves.  (The second case was missed until

@@ -42,16 +42,12 @@ constexpr int kThreads = 256;           // 4 wavefronts per workgroup
 // instantiation fits without spilling, the compositing one spills 4 registers).  The 64-pixel
 // kernel is limited by its 48 KB of LDS, not by registers.  (r01 A/B, same box.)
 constexpr int kWavesPerSimd16 = 7, kWavesPerSimd32 = 6;   // (32-pixel tiles: 28.7 KB of LDS = 5 workgroups per CU)
-// the 32-pixel kernels with one path each (raster.hip, kPath*): the pixel owners alone fit seven wavefronts
-// (72 registers, 19.5 KB of LDS); the small records' kernel carries its row spans in 31.8 KB of LDS: five
-// workgroups per CU, and the registers that leaves
+// the 32-pixel kernel with the pixel owners alone (raster.hip, kPathOwners): seven wavefronts (72 registers,
+// 19.5 KB of LDS)
 #ifndef CRENDER_WAVES_OWNERS
 #define CRENDER_WAVES_OWNERS 7
 #endif
-#ifndef CRENDER_WAVES_SMALL
-#define CRENDER_WAVES_SMALL 5
-#endif
-constexpr int kWavesPerSimdOwners = CRENDER_WAVES_OWNERS, kWavesPerSimdSmall = CRENDER_WAVES_SMALL;
+constexpr int kWavesPerSimdOwners = CRENDER_WAVES_OWNERS;
 constexpr int kItemPixels = 2;      // samples per work item of the per-pixel sweep of 16-pixel tiles
 #ifndef CRENDER_ITEM32
 #define CRENDER_ITEM32 2

@@ -95,6 +95,9 @@ struct crender_plan {
     // which raster kernel a 32-pixel plan's frames get (raster.hip, kPath*): forced by the caller (-1: not),
     // else suggested by the size classes its last reported frame counted; what the last launch was
     int forced_path = -1, auto_path = 0, last_path = 0;
+    bool last_ordered = false;            // the last raster launch left a dispatch order (crender_plan_debug_check)
+    bool auto_known = false;              // auto_path comes from a record (else from the triangle count per tile)
+    uint64_t hint_ticket = 0;             // the launch whose record was taken last
     uint32_t *stats(int par) const { return reinterpret_cast<uint32_t *>(ws + L.off_stats) + (size_t)par * kStatWords; }
     uint32_t *hint(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_hint) + 4 * k; }
     uint32_t *order(int k) const { return reinterpret_cast<uint32_t *>(ws + L.off_order) + (size_t)k * L.g.ntiles; }
@@ -142,6 +145,10 @@ struct crender_pipeline {
     bool timing() const { return (size_t)(timed_frames + 1) * 2 <= events.size(); }
     const void *last_tri = nullptr, *last_nrm = nullptr;
     int64_t last_T = -1;
+    // which raster kernel the chain's frames get when left to the plans (kPath*, raster.hip): the newest
+    // opinion any of the chain's plans has read from its records — they all render the same stream of frames
+    int shared_path = 0;
+    bool shared_known = false;
     hipStream_t last_caller = nullptr;
     bool synced = false;
     struct Bound {   // crender_pipeline_bind
@@ -165,6 +172,7 @@ namespace crender_detail {
 int bin_pass(crender_plan *plan, bool project, const float *d_tri, const float *d_nrm, int64_t T,
              const float *P16, unsigned flags, void *stream, SetupArgs *defer = nullptr,
              bool *deferred = nullptr);
+bool raster_path_hint(crender_plan *plan);
 int raster_pass(crender_plan *plan, const float *proj, const float *d_col, const float *d_nrm, int64_t T,
                 float *d_z, float *d_color, float *d_normal, int32_t *d_winner, unsigned flags,
                 void *stream, const SetupArgs *with_setup = nullptr);

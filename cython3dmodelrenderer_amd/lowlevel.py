@@ -105,9 +105,14 @@ class Plan:
         """0 = count / scan / fill, 1 = direct bins, 2 = pair bins."""
         return int(self._lib.crender_plan_last_frame_binning(self.handle))
 
+    def debug_check(self):
+        """crender_plan_debug_check on the current stream: raises if the plan's cross-frame state is inconsistent."""
+        with torch.cuda.device(self.device):
+            _capi.plan_debug_check(self.handle, _stream(self.device))
+
     def set_raster_path(self, path):
-        """-1 = the plan chooses (default), 0 = general kernel, 1 = pixel owners only, 2 = small records only;
-        every choice renders every tile exactly (crender_plan_set_raster_path)."""
+        """-1 = the plan chooses (default), 0 = general kernel, 1 = pixel owners only; every choice renders
+        every tile exactly (crender_plan_set_raster_path)."""
         _capi.check(self._lib.crender_plan_set_raster_path(self.handle, int(path)), "crender_plan_set_raster_path")
 
     def last_raster_path(self):

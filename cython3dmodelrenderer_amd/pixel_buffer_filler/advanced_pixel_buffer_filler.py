@@ -325,7 +325,7 @@ class AdvancedPixelBufferFiller:
         # alone gets (a quarter of the workgroups).  (bench.py's A/B sets it.)
         self._pipeline_tile = None
         # Which raster kernel the plans' frames get (crender_plan_set_raster_path): None = each plan chooses
-        # by the size classes its previous frames counted; 0 / 1 / 2 = general / pixel owners / small records.
+        # by the size classes its previous frames counted; 0 / 1 = general / pixel owners.
         # Speed only: every kernel renders every tile exactly.
         self._raster_path = raster_path
         self._order = None             # (orig_of, pos_of) int32 device tensors of the resident inputs
@@ -398,9 +398,17 @@ class AdvancedPixelBufferFiller:
                                                           C.byref(cap)), "crender_plan_last_bin_usage")
         self._plan_capacity = cap.value
 
+    def debug_check(self):
+        """Settles everything in flight, then checks the cross-frame state of every plan this filler owns
+        (crender_plan_debug_check): raises CrenderError with the findings."""
+        self.synchronize()
+        with torch.cuda.device(self.device):
+            for plan in ([self._plan] if self._plan else []) + (list(self._pipe.plans) if self._pipe is not None else []):
+                _capi.plan_debug_check(plan, self._stream())
+
     def last_raster_paths(self):
         """Which raster kernel the most recent launch of every live plan was (crender_plan_last_raster_path:
-        0 general, 1 pixel owners, 2 small records): the single-stream plan first, then the swap chain's."""
+        0 general, 1 pixel owners): the single-stream plan first, then the swap chain's."""
         plans = ([self._plan] if self._plan else []) + (list(self._pipe.plans) if self._pipe is not None else [])
         return [int(self._lib.crender_plan_last_raster_path(p)) for p in plans]
 
@@ -789,15 +797,23 @@ class AdvancedPixelBufferFiller:
             # again (the rewrite was enqueued there) and what was binned ahead from the old contents is
             # dropped; a tile-coherent SNAPSHOT of the arrays is taken anew.  (The caller still must not
             # rewrite arrays that frames in flight are reading: join() first.)
+            # The arrays are bound ANEW whether or not they are sorted: a model may have REPLACED one of them
+            # (DeviceModel.set_uniform_color and the texture path make a new colour tensor and count it as a
+            # rewrite) — until round 6 an unsorted resident model kept rendering the old tensor here.
             self._join_pipe()
-            if self._order is not None:
-                src = (model._vertices_by_triangles, model._colors_by_triangles, model._normals_by_triangles)
-                inputs = self._upload(src, ("model._vertices_by_triangles", "model._colors_by_triangles",
-                                            "model._normals_by_triangles"), composite=False)
+            was_sorted = self._order is not None
+            src = (model._vertices_by_triangles, model._colors_by_triangles, model._normals_by_triangles)
+            inputs = self._upload(src, ("model._vertices_by_triangles", "model._colors_by_triangles",
+                                        "model._normals_by_triangles"), composite=False)
+            if was_sorted:
                 self._inputs, self._order = self._tile_coherent(inputs, False, model.generation)
                 self._inputs_private = self._order is not None
-                self._inputs_stage = None
-            elif self._pipe is not None:
+            else:
+                self._inputs = inputs
+                self._inputs_private = False
+            self._inputs_stage = None
+            self._input_key = None
+            if self._pipe is not None:
                 self._pipe._args = None          # every slot is bound again: a binding voids its look-ahead
             self._model_generation = model.generation
         use_pipe = self._pipeline if pipelined is None else (pipelined and self._pipeline)

@@ -44,7 +44,8 @@ enum {
     CRENDER_EINVAL = 1,  /* bad argument (null pointer, negative size, bad strip) */
     CRENDER_EHIP = 2,    /* HIP runtime error; text in crender_last_error()       */
     CRENDER_ENOMEM = 3,  /* workspace smaller than crender_plan_workspace_bytes   */
-    CRENDER_EBUSY = 4    /* crender_plan_poll_bin_usage: that frame's record has not landed yet */
+    CRENDER_EBUSY = 4,   /* crender_plan_poll_bin_usage: that frame's record has not landed yet */
+    CRENDER_ESTATE = 5   /* crender_plan_debug_check: the plan's cross-frame state is inconsistent */
 };
 
 /* flags of crender_raster / crender_render_model / crender_raster_atomic */
@@ -194,16 +195,15 @@ CRENDER_API int crender_plan_set_normal_z(crender_plan *plan, const float *d_nz)
 
 /* Which raster kernel a plan's frames get (no reference counterpart: the reference has one loop nest,
  * .pyx:196-244, and so has every kernel here — the choice is about speed only).  Plans on 32-pixel tiles
- * have three kernels that all render EVERY tile exactly (the parity tests force each through every scene):
+ * have two kernels that both render EVERY tile exactly (the parity tests force each through every scene):
  *   0  the general one, every sweep in it (6 wavefronts per SIMD);
  *   1  the pixel owners alone — frames of large triangles (bunny 4096^2, T-Rex 8192^2): no key plane, 19.5 KB
- *      of LDS, 7 wavefronts per SIMD;
- *   2  the run-wise sweep over exact row spans alone — frames of small triangles (10 M-triangle soups,
- *      T-Rex 1024^2 on a swap chain's 32-pixel plans): samples surely outside a triangle never become work.
+ *      of LDS, 7 wavefronts per SIMD.
  * -1 (the default) lets the plan choose: every raster launch counts its covered tiles by the size of their
  * records and leaves the counts in the launch's usage record (crender_plan_poll_bin_usage's pinned memory);
- * the plan reads its own last landed record before a launch — no copy, no synchronisation — and takes 1 or
- * 2 when three quarters of the tiles are of that kind, else 0.  The first frames of a plan get 0.
+ * a plan reads its own (a swap chain: its plans') last landed record before a launch — no copy, no
+ * synchronisation — and takes 1 when three quarters of the covered tiles hold large records, else 0; until a
+ * record has landed, the triangle count per tile decides (few triangles on many tiles are large ones).
  * Other tile sizes have the general kernel only and ignore the setting.
  *   crender_plan_set_raster_path      fix the kernel of this plan's frames, or hand the choice back (-1)
  *   crender_plan_last_raster_path     which kernel the most recent raster launch of the plan was
@@ -216,6 +216,18 @@ CRENDER_API int crender_set_default_raster_path(int path);
 /* Light direction (host pointer to 3 floats, copied) for frames rendered with CRENDER_FUSED_GURO:
  * GuroIllumination.__init__'s light_direction (guro_illumination.py:6-18). */
 CRENDER_API int crender_plan_set_light(crender_plan *plan, const float *light3);
+
+/* Diagnostics (no reference counterpart: the reference keeps no state between render_model calls but its
+ * buffers, .pyx:92-104).  A plan does: two parities of per-tile counters, the split tiles' flag and helper-slot
+ * words, registration / hint_bad counters, the dispatch order, the ring of usage records.  This synchronises
+ * `stream`, reads that state back and checks its invariants for the moment between two frames — after a
+ * raster launch: the next frame's counters, registration counter and hint_bad all zero, no split flag and
+ * no helper slot left set; after a binning pass alone (crender_prepare, a swap chain's look-ahead): helper
+ * triples = registrations = tiles whose list reached the threshold, each flagged once; always: the dispatch
+ * order is a permutation that agrees with its header and `grouped` bytes, every landed usage record is one of
+ * this plan's launches, in its slot, leading and trailing sequence words alike.  CRENDER_OK, or CRENDER_ESTATE
+ * with the findings as text in `msg` (may be NULL).  Not for the frame path: it copies the plan's head. */
+CRENDER_API int crender_plan_debug_check(crender_plan *plan, void *stream, char *msg, size_t msg_bytes);
 
 /* Measurement aid (no reference counterpart): record HIP events on the frame's own
  * stream around the binning passes and around the raster kernel of each of the next

@@ -42,7 +42,7 @@ def oracle_frame(O, tri, col, nrm, H, W, fov=45.0, strips=None, prior=None):
 
 
 def gpu_frame(hip, tri, col, nrm, H, W, fov=45.0, mode="fused", tile=0, strips=None, prior=None,
-              clear=False, bin_capacity=0):
+              clear=False, bin_capacity=0, raster_path=None):
     """mode: 'fused' = crender_render_model, 'split' = crender_project + crender_raster,
     'atomic' = crender_project + crender_raster_atomic; 'fused-scan' / 'split-scan' force the
     count / scan / fill binning passes (CRENDER_NO_DIRECT_BINS)."""
@@ -62,6 +62,8 @@ def gpu_frame(hip, tri, col, nrm, H, W, fov=45.0, mode="fused", tile=0, strips=N
             hip.raster_atomic(proj, c, n, fb, y0=y0, y1=y1, clear=clear)
             continue
         plan = hip.Plan(H, W, max(len(tri), 1), y0=y0, y1=y1, tile=tile, bin_capacity=bin_capacity)
+        if raster_path is not None:
+            plan.set_raster_path(raster_path)
         for attempt in range(2):
             if mode == "fused":
                 hip.render_model(plan, t, c, n, P, fb, clear=clear, direct_bins=direct, flags=extra)
@@ -73,6 +75,8 @@ def gpu_frame(hip, tri, col, nrm, H, W, fov=45.0, mode="fused", tile=0, strips=N
             # only the direct bins may overflow here; the plan has switched itself to the
             # general path and the frame is simply rendered again (exact: per-pixel minimum)
             assert attempt == 0 and plan.last_frame_direct(), (need, cap)
+        if raster_path is not None and tile == 32:
+            assert plan.last_raster_path() == raster_path
     z, cb, nb, win = fb.numpy()
     return z, cb, nb, win, (proj.cpu().numpy() if proj is not None else None)
 
@@ -453,6 +457,8 @@ def test_fuzz_many_frames_on_the_same_plans(hip, oracle, seed):
                     if how == "prepare twice" and dev[other][0].shape[0]:
                         hip.prepare(plan, dev[other][0], dev[other][2], P, direct_bins=direct)   # never drawn
                     hip.prepare(plan, t, n, P, direct_bins=direct)
+                    if k % 3 == 0:
+                        plan.debug_check()      # binned, not drawn: registrations = flags = helper triples = long lists
                     hip.draw(plan, c, n, T, fb, clear=clear, direct_bins=direct)
                 need, cap = plan.bin_usage()
                 if need <= cap:
@@ -460,6 +466,13 @@ def test_fuzz_many_frames_on_the_same_plans(hip, oracle, seed):
                 assert attempt == 0, (need, cap, history)      # a plan switches to roomier bins once
         z, cb, nb, win = fb.numpy()
         what = f"stateful fuzz {seed}: {H}x{W} tile {tile} strips {strips}, frame {k} of {history}"
+        for plan in plans:
+            # the state a frame LEAVES, checked as such (crender_plan_debug_check) — before any pixel of a later
+            # frame could show it
+            try:
+                plan.debug_check()
+            except Exception as e:
+                raise AssertionError(f"{what}: {e}") from e
         assert_bit_equal(z, ref.z_buffer, what + ": z")
         assert_bit_equal(cb, ref.color_buffer, what + ": colour")
         assert_bit_equal(nb, ref.normals_buffer, what + ": normal")
@@ -520,6 +533,7 @@ def test_fuzz_a_filler_through_a_random_session(oracle, hip, seed):
     resident = None                     # what render_frame renders: the arrays of the last render call
 
     def check(what):
+        f.debug_check()                 # every plan's cross-frame state (crender_plan_debug_check), then the pixels
         for name, get, want in (("z", f.get_z_buffer, ref.z_buffer), ("colour", f.get_color_buffer, ref.color_buffer),
                                 ("normal", f.get_normals_buffer, ref.normals_buffer)):
             views[name] = get()
@@ -1104,6 +1118,13 @@ def test_lone_chain_through_changing_scenes(oracle, hip, res, tile, clear, depth
                 "frame")
             if k % 3 != 1:            # (frames in a row without a join now and then)
                 _capi.check(lib.crender_pipeline_join(pipe, stream), "join")
+                torch.cuda.synchronize()
+                for q_, plan in enumerate(plans):     # rasterized plans and plans binned ahead alike: their state first
+                    try:
+                        plan.debug_check()
+                    except Exception as e:
+                        raise AssertionError(f"frame {k} ({name} after {order[k - 1] if k else '-'}), plan {q_}, {res}^2, "
+                                             f"tile {tile}, clear={clear}, depth {depth}, flags {flags}: {e}") from e
                 for s_, (r_, b_) in enumerate(zip(refs, fbs)):
                     z, cc, nn, w = b_.numpy()
                     what = (f"frame {k} ({name} after {order[k - 1] if k else '-'}), set {s_}, {res}^2, tile {tile}, "
@@ -1215,6 +1236,12 @@ def test_fuzz_renderers_sharing_one_filler(oracle, seed):
             got = img.cpu().numpy() if isinstance(img, torch.Tensor) else img
             story_last_inputs = pool[name]
         what = f"renderer session {seed} ({H}x{W}, {kw}, light {direction}), step {step} of {story}"
+        if got is not None and isinstance(got, np.ndarray):
+            got = got.copy()            # (the check below settles the filler: keep what this step returned)
+        try:
+            filler.debug_check()        # the plans' cross-frame state (crender_plan_debug_check), then the pixels
+        except Exception as e:
+            raise AssertionError(f"{what}: {e}") from e
         assert_bit_equal(got, ref.color_buffer, what + ": colour")
         assert_bit_equal(filler.get_z_buffer(), ref.z_buffer, what + ": z")
         assert_bit_equal(filler.get_normals_buffer(), ref.normals_buffer, what + ": normal")
@@ -1379,6 +1406,10 @@ def test_dispatch_order_hint_never_changes_pixels(hip, oracle, clear, tile):
             hip.render_model(plan, z, z, z, P, fb, clear=clear)
         need, cap = plan.bin_usage()
         assert need <= cap and plan.last_frame_direct()
+        try:
+            plan.debug_check()          # the state this frame leaves (crender_plan_debug_check), before any pixel shows it
+        except Exception as e_:
+            raise AssertionError(f"frame {k} on one plan (clear={clear}, tile={tile}): {e_}") from e_
         compare(tuple(fb.numpy()) + (None,), ref, f"frame {k} on one plan (clear={clear}, tile={tile})")
 
 
@@ -2284,9 +2315,16 @@ def test_fuzz_a_device_model_moved_between_renders(oracle, seed):
 
     rendered = False
     for step in range(26):
-        op = str(rng.choice(["shift", "shift", "scale", "render", "render", "render clear", "frames", "frames", "check"]))
+        op = str(rng.choice(["shift", "shift", "scale", "render", "render", "render clear", "frames", "frames", "check",
+                             "recolour"]))
         story.append(op)
-        if op in ("shift", "scale"):
+        if op == "recolour":
+            # a NEW colour tensor behind the model (set_uniform_color replaces the array and counts it as a
+            # rewrite): the next render_frame must render it — it rendered the old one on unsorted models
+            filler.join()
+            bgr = tuple(float(v) for v in rng.uniform(10, 250, 3))
+            hm.set_uniform_color(bgr); dm.set_uniform_color(bgr)
+        elif op in ("shift", "scale"):
             filler.join()
             if op == "shift":
                 v = [float(rng.uniform(-0.08, 0.08)), float(rng.uniform(-0.08, 0.08)), float(rng.uniform(-0.1, 0.2))]
@@ -2309,6 +2347,10 @@ def test_fuzz_a_device_model_moved_between_renders(oracle, seed):
             ref.render_arrays(*host_arrays())
         if op in ("check", "frames", "render", "render clear") and rendered:
             what = f"device-model session {seed} ({H}x{W}, {kw}), step {step} of {story}"
+            try:
+                filler.debug_check()    # the plans' cross-frame state (crender_plan_debug_check), then the pixels
+            except Exception as e:
+                raise AssertionError(f"{what}: {e}") from e
             assert_bit_equal(dm._vertices_by_triangles.cpu().numpy(), hm._vertices_by_triangles, what + ": the arrays")
             assert_bit_equal(filler.get_z_buffer(), ref.z_buffer, what + ": z")
             assert_bit_equal(filler.get_color_buffer(), ref.color_buffer, what + ": colour")
@@ -2569,3 +2611,98 @@ def test_normal_z_array_feeds_the_back_face_test(oracle):
     filler._order[2].fill_(1.0)                  # every triangle now "faces away"
     filler.render_frame(pipelined=False)
     assert float(filler.get_z_buffer().min()) == 1e6, "the back-face test read the array it was given"
+
+
+# ---- the raster kernels of a 32-pixel plan (crender_plan_set_raster_path): each exact on every tile ----------
+# (scripts/r6_paths.sh also runs this whole file once per kernel, CRENDER_RASTER_PATH = 0 / 1)
+@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("name,fixture,res", SCENES)
+@pytest.mark.parametrize("mode", ["fused", "fused-scan", "split"])
+def test_every_raster_kernel_renders_every_scene(hip, oracle, golden, name, fixture, res, mode, path):
+    tri, col, nrm = scene(fixture)
+    f = oracle_frame(oracle, tri, col, nrm, res, res)
+    got = gpu_frame(hip, tri, col, nrm, res, res, mode=mode, tile=32, raster_path=path)
+    compare(got, f, f"{name}/{mode}/path {path}")
+    g = golden["scenes"][name]
+    assert (sha(got[0]), sha(got[1]), sha(got[2]), sha(got[3])) == (g["z"], g["c"], g["n"], g["winner"])
+
+
+@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("seed,T,H,W,px,kw", [
+    (3, 5000, 256, 256, (0.3, 4), {}),                # tiny records through the pixel owners
+    (5, 300, 512, 512, (100, 600), {}),               # huge ones
+    (6, 3000, 333, 517, (0.5, 200), {"margin": 1.0}), # mixed sizes, ragged frame
+    (8, 9000, 96, 64, (1, 30), {}),                   # six tiles, ~2 000 records each: lists of many batches
+])
+@pytest.mark.parametrize("how", ["clear", "composite", "strips"])
+def test_every_raster_kernel_on_soups_composites_and_strips(hip, oracle, seed, T, H, W, px, kw, how, path):
+    """The pixel owners' kernel takes EVERY tile its plan holds: lists of more than one batch (the pixels'
+    running minimum stays in registers across the batches, each batch stores what it won), small records,
+    frames that composite onto a prior buffer, row strips that cut tiles."""
+    rng = np.random.default_rng(seed)
+    tri, col, nrm = random_soup(rng, T, max(H, W), size_px=px, **kw)
+    prior = None
+    if how == "composite":
+        prior = (rng.uniform(0.5, 2.5, (H, W)).astype(np.float32),
+                 rng.uniform(0, 255, (H, W, 3)).astype(np.float32), rng.standard_normal((H, W, 3)).astype(np.float32))
+        prior[0][::7, ::5] = np.nan                   # a NaN already in the buffer loses to every fragment
+    strips = [(0, 37), (37, H - 13), (H - 13, H)] if how == "strips" else None
+    f = oracle_frame(oracle, tri, col, nrm, H, W, strips=strips, prior=prior)
+    for mode in ("fused", "fused-scan"):
+        got = gpu_frame(hip, tri, col, nrm, H, W, mode=mode, tile=32, strips=strips, prior=prior,
+                        clear=(how == "clear"), raster_path=path)
+        compare(got, f, f"soup{seed}/{how}/{mode}/path {path}", check_winner=(how != "composite"))
+
+
+def test_plans_pick_their_raster_kernel_from_what_their_frames_count(hip, oracle):
+    """crender_plan_set_raster_path(-1), the default: a plan's first launches go by the triangle count per tile,
+    later ones by the size classes the tiles themselves counted (the launch's usage record carries the sums of
+    the launch before it).  bunny 2048^2 — 7 triangles per tile, but large ones — starts on the general kernel
+    and moves to the pixel owners with its third frame; T-Rex 1024^2 on 32-pixel tiles stays; the cube (12
+    triangles) starts with the owners.  Whatever the kernel, the pixels are the oracle's."""
+    for fixture, res, want in (("bunny_inputs.npz", 2048, [0, 0, 1, 1]), ("trex_inputs.npz", 1024, [0, 0, 0, 0]),
+                               ("cube_inputs.npz", 256, [1, 1, 1, 1])):
+        tri, col, nrm = scene(fixture)
+        f = oracle_frame(oracle, tri, col, nrm, res, res)
+        P = hip.projection_matrix(45.0, 0.1, 1000.0, res, res)
+        t, c, n = _dev(tri), _dev(col), _dev(nrm)
+        plan = hip.Plan(res, res, len(tri), tile=32)
+        paths = []
+        for k in range(4):
+            fb = hip.FrameBuffers(res, res)
+            hip.render_model(plan, t, c, n, P, fb, clear=True)
+            got = fb.numpy()                          # (synchronises: the launch's record has landed)
+            paths.append(plan.last_raster_path())
+            compare(got + (None,), f, f"{fixture} frame {k} on kernel {paths[-1]}")
+        assert paths == want, (fixture, paths)
+        plan.set_raster_path(0)                       # the caller's word goes first, and -1 hands the choice back
+        fb = hip.FrameBuffers(res, res)
+        hip.render_model(plan, t, c, n, P, fb, clear=True)
+        compare(fb.numpy() + (None,), f, "forced general")
+        assert plan.last_raster_path() == 0
+        plan.set_raster_path(-1)
+        hip.render_model(plan, t, c, n, P, fb, clear=True)
+        fb.numpy()
+        assert plan.last_raster_path() == want[-1]
+
+
+def test_a_swap_chain_shares_what_one_plan_learnt(oracle):
+    """The plans of a swap chain (two per slot with look-ahead) render the same stream of frames: the size class one
+    of them has read from its records is every plan's from its next launch on (crender_pipeline_frame)."""
+    from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
+    tri, col, nrm = scene("bunny_inputs.npz")
+    res = 2048
+    f = oracle_frame(oracle, tri, col, nrm, res, res)
+    filler = AdvancedPixelBufferFiller(res, res, fov=45.0, pipeline=True, pipeline_depth=3, track_winner=True)
+    filler.render_arrays(tri, col, nrm, clear=True)
+    filler.synchronize()
+    for k in range(14):
+        filler.render_frame()
+        if k % 3 == 2:
+            filler.synchronize()
+            assert_bit_equal(filler.get_z_tensor().cpu().numpy(), f.z_buffer, f"frame {k}: z")
+            assert_bit_equal(filler.get_color_tensor().cpu().numpy(), f.color_buffer, f"frame {k}: colour")
+    filler.synchronize()
+    paths = filler.last_raster_paths()
+    assert len(paths) == 1 + 6 and paths[1:] == [1] * 6, paths
+    assert_bit_equal(filler.get_normals_tensor().cpu().numpy(), f.normals_buffer, "normal")
