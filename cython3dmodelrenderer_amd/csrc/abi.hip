@@ -476,7 +476,10 @@ int crender_plan_debug_check(crender_plan *plan, void *stream, char *msg, size_t
         }
         if (dup || oob) say("the dispatch order is no permutation (%d repeated, %d out of range)", dup, oob);
         const uint32_t ns = hint[1];
-        if (ns > (uint32_t)nt) say("order header: %u tiles with a workgroup of their own of %d", ns, nt);
+        // (hint[0] == 0: the launch reads no order — an empty frame's, or a header a binning pass that started the
+        // plan over has zeroed: nothing to agree with)
+        if (hint[0] == 0) { }
+        else if (ns > (uint32_t)nt) say("order header: %u tiles with a workgroup of their own of %d", ns, nt);
         else if (!dup && !oob) {
             int wrong = 0;
             for (int i = 0; i < nt; ++i)

@@ -487,10 +487,21 @@ CR_DEV bool load_record(const TileLists &L, const float *__restrict__ proj, cons
     return true;
 }
 
-// One covered tile's size class into the frame's statistics (see TileLists::stats): called by one lane.
-CR_DEV void count_tile_class(const TileLists &L, bool large)
+// One covered tile's size class into the frame's statistics (see TileLists::stats): called by ONE lane, as the
+// LAST memory operation of its wavefront.  (In the middle of the tile's chain — where the class is known — the
+// atomic sat in front of every later load in the wavefront's in-order memory counter: a device-scope atomic on
+// a word 78 workgroups share takes microseconds to come back, and the lone T-Rex 1024^2 launch took 18.4 us
+// instead of 15.3; profiles/r06/ab_stats_atomics.txt.)
+CR_DEV void count_tile_class(const TileLists &L, int cls)
 {
-    if (L.stats) atomicAdd(&L.stats[(((blockIdx.x >> 3) & (kStatSlots - 1)) << 1) + (large ? 0u : 1u)], 1u);
+    if (L.stats && cls >= 0) atomicAdd(&L.stats[(((blockIdx.x >> 3) & (kStatSlots - 1)) << 1) + (uint32_t)cls], 1u);
+}
+// 0: the first wavefront's share of the list is, on average, records of 16 blocks and more; 1: smaller ones
+CR_DEV int tile_class_of(uint32_t incl_blocks, uint32_t nrec)
+{
+    const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)incl_blocks, 63);
+    const uint32_t n0 = nrec < 64u ? nrec : 64u;
+    return tot0 >= 16u * n0 ? 0 : 1;
 }
 
 // ---- dispatch order from the previous frame's coverage -------------------------------------
@@ -791,8 +802,9 @@ constexpr size_t raster_queue_bytes()
 // Which tile workgroup `b` of a raster launch takes, and which part of it; false: the workgroup is done
 // (it built the dispatch order, found its helper slot empty, or cleared its group of empty tiles).
 template <int TS, bool CLEAR>
-CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad, bool &helper_out)
+CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad, bool &helper_out, bool &likely_out)
 {
+    likely_out = false;      // the tile surely (a helper's) or probably (the order's covered section) has records
     const TileLists &L = c.L;
     const Geom &G = c.G;
     float *const zb = c.zb, *const cb = c.cb, *const nb = c.nb;
@@ -849,6 +861,7 @@ CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad
         if (v == 0) return false;                        // (same word for every thread: uniform)
         tile = (int)v - 1;
         quad = 1 + b % 3;
+        likely_out = true;
     } else {
         const int m = b < lead ? b : b - used;
         if (m == 0 && tid == 0) {
@@ -879,6 +892,7 @@ CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad
             const int ns = (int)L.hint[1], ng = (int)L.hint[2];
             if (m < ns) {
                 tile = (int)L.order[m];
+                likely_out = true;
             } else {
                 // the order's last section: up to kGroup empty tiles per workgroup, cleared with two
                 // float4 stores per thread and tile (no list to look at: the binning pass vouches
@@ -1233,8 +1247,9 @@ struct OwnerQueue {
 // eight words — denominators, reciprocals, signs, window flag, and which of the four wavefronts' bands of
 // eight rows the triangle can touch at all (owner_path32's, here straight from the registers the record
 // was loaded into: no barrier between the queue and the words).
-CR_DEV void owners_queue(const Tile<32> &c, uint32_t base, bool first)
+CR_DEV int owners_queue(const Tile<32> &c, uint32_t base, bool first)
 {
+    int tile_class = -1;
     [[maybe_unused]] constexpr int TS = 32;
     CR_TILE_LOCALS(c);
     OwnerQueue &oq = *reinterpret_cast<OwnerQueue *>(qraw);
@@ -1256,11 +1271,8 @@ CR_DEV void owners_queue(const Tile<32> &c, uint32_t base, bool first)
             box_wh = (uint32_t)(xr - xl) | ((uint32_t)(yb - yt) << 16);
         }
     }
-    if (first && wave == 0) {      // the tile's size class (TileLists::stats)
-        const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_sum((uint32_t)blocks_of(box_wh)), 63);
-        const uint32_t n0 = end - beg < 64u ? end - beg : 64u;
-        if (lane == 0) count_tile_class(L, tot0 >= 16u * n0);
-    }
+    if (first && __builtin_amdgcn_readfirstlane(wave) == 0)    // the tile's size class (TileLists::stats), reported at the tile's end
+        tile_class = tile_class_of(wave_incl_sum((uint32_t)blocks_of(box_wh)), end - beg);
     if (!first) __syncthreads();    // the previous batch's readers are done with the queue
     oq.x0[tid] = t.x0; oq.y0[tid] = t.y0; oq.z0[tid] = t.z0;
     oq.x1[tid] = t.x1; oq.y1[tid] = t.y1; oq.z1[tid] = t.z1;
@@ -1288,6 +1300,7 @@ CR_DEV void owners_queue(const Tile<32> &c, uint32_t base, bool first)
     o[0] = make_float4(st.l03, st.l13, st.l23, __uint_as_float(flags));
     o[1] = make_float4(st.fast ? st.r1 : 0.0f, st.r2, st.r3, 0.0f);
     __syncthreads();
+    return tile_class;
 }
 
 // A list of more than one batch (rare where this kernel is chosen; this path may spill, the one-batch
@@ -1310,8 +1323,10 @@ CR_DEV void owners_batches(const Tile<32> &c)
         if (!CLEAR && Y < Y1 && Xs + XS * j < X1) best[j] = make_key(zord_prior(*elem(zb, (I)(pix0 + XS * j))), KEY_LOW_PRIOR);
     }
     const uint32_t my_band = 1u << (tid >> 6);
+    int tile_class = -1;
     for (uint32_t base = beg; base < end; base += kThreads) {
-        owners_queue(c, base, base == beg);
+        const int cls = owners_queue(c, base, base == beg);
+        if (base == beg) tile_class = cls;
         if (base == beg) CR_STAMP(6);
         const int nrec = (int)((end - base) < (uint32_t)kThreads ? (end - base) : (uint32_t)kThreads);
         // ---- the owners walk the batch (owner_tile's loop) ---------------------------------------------
@@ -1424,6 +1439,7 @@ CR_DEV void owners_batches(const Tile<32> &c)
             if (wp) wp[o] = -1;
         }
     }
+    if (tid == 0) count_tile_class(L, tile_class);
     CR_STAMP(3);
 }
 
@@ -1691,8 +1707,8 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     // ---- which tile, and which part of it (grid = [order builder, if ordered][3 * hmax helpers][ntiles
     // main workgroups, one tile each])
     int tile, quad;
-    bool helper;
-    if (!pick_tile<TS, CLEAR>(c, b, b, tile, quad, helper)) return;
+    bool helper, likely;
+    if (!pick_tile<TS, CLEAR>(c, b, b, tile, quad, helper, likely)) return;
     const int ty = G.ntx_magic ? (int)__umulhi((uint32_t)tile, G.ntx_magic) : tile / G.ntx;
     const int tx = tile - ty * G.ntx;
     int X0 = tx * TS, Y0 = G.y0 + ty * TS;
@@ -1705,6 +1721,22 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
         g_stamps[stamp_base + 7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID
         g_stamps[stamp_base + 8] = (unsigned long long)tile;
         g_stamps[stamp_base + 10] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+    // Small frames rendered alone (ordered launches on 32-pixel direct-bin plans): a workgroup whose tile the
+    // previous frame's order lists as covered — or a helper, whose tile THIS frame's binning registered — asks
+    // for its slot's entry of the first batch TOGETHER with the list length instead of after it: one dependent
+    // round trip (~0.7-1 us of a quadrant's 8.6, profiles/r05/stamps_kframe32_trex1024.txt) off the chain.
+    // What the slab holds beyond the list is an older frame's entry: loaded, never used.
+    [[maybe_unused]] float4 se0{}, se1{}, se2{};
+    [[maybe_unused]] bool spec = false;
+#ifndef CRENDER_NO_SPEC_LOADS
+    if constexpr (TS == 32 && PATH == kPathGeneral) {
+        spec = likely && !L.offs && !L.pairs && L.capacity >= (uint32_t)kThreads;
+        if (spec) {
+            const float4 *e = L.bins + ((size_t)tile * L.capacity + (size_t)tid) * 3;
+            se0 = e[0]; se1 = e[1]; se2 = e[2];
+        }
     }
 #endif
     // the tile's triangle list: a run of the scanned index array, or (direct bins, offs == null)
@@ -1763,7 +1795,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
         c.X0 = X0; c.Y0 = Y0; c.X1 = X1; c.Y1 = Y1; c.rw = rw; c.quad = quad; c.beg = beg; c.end = end;
         CR_STAMP(1);
         if (end - beg <= (uint32_t)kThreads) {
-            owners_queue(c, beg, true);
+            const int tile_class = owners_queue(c, beg, true);
             CR_STAMP(6);
             const OwnerQueue &oq = *reinterpret_cast<const OwnerQueue *>(qraw);
             const float *pre = reinterpret_cast<const float *>(key);
@@ -1773,6 +1805,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
             else
                 owner_tile<CLEAR, size_t, OwnerQueue>(oq, pre, (int)(end - beg), col, nrm, L.pos_of, L.light, zb, cb, nb, win,
                                                       G.W, X0, Y0, X1, Y1);
+            if (tid == 0) count_tile_class(L, tile_class);
             CR_STAMP(3);
         } else {
             owners_batches<CLEAR, size_t>(c);
@@ -1786,7 +1819,15 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     uint32_t cur_id = 0, cur_bx = 0, cur_by = 0;
     TriXYZ cur_t{};
     bool cur_ok = tid < kBatch && beg + tid < end;
-    if (cur_ok) cur_ok = load_record(L, proj, G, beg + tid, cur_id, cur_t, cur_bx, cur_by);
+    if (spec) {
+        // (load_record's direct-bin branch on the entry asked for above)
+        cur_t = TriXYZ{se0.x, se0.y, se0.z, se0.w, se1.x, se1.y, se1.z, se1.w, se2.x};
+        cur_id = __float_as_uint(se2.y);
+        cur_bx = __float_as_uint(se2.z);
+        cur_by = __float_as_uint(se2.w);
+        cur_ok = cur_ok && cur_id < L.T;
+        if (cur_ok && L.orig_of) cur_id = L.orig_of[cur_id];
+    } else if (cur_ok) cur_ok = load_record(L, proj, G, beg + tid, cur_id, cur_t, cur_bx, cur_by);
 
     c.X0 = X0; c.Y0 = Y0; c.X1 = X1; c.Y1 = Y1; c.rw = rw; c.quad = quad; c.beg = beg; c.end = end;
     // (32-pixel tiles: the keys once it is known that the tile is not the pixel owners', see below)
@@ -1799,6 +1840,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     }
 #endif
 
+    [[maybe_unused]] int tile_class = -1;        // (wavefront 0 learns it with the first batch, reports it last)
     for (uint32_t base = beg; base < end; base += kBatch) {
         // ---- queue this batch: one record per thread, slot = thread index --------------
         uint32_t box_xy = 0, box_wh = 0;
@@ -1849,11 +1891,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
         const uint32_t incl = wave_incl_sum(my_blocks);
         if constexpr (TS == 32) {
             // the tile's size class for the next frames' choice of kernel: the first wavefront's records
-            if (base == beg && wave == 0) {
-                const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                const uint32_t n0 = end - beg < 64u ? end - beg : 64u;
-                if (lane == 0) count_tile_class(L, tot0 >= 16u * n0);
-            }
+            if (base == beg && __builtin_amdgcn_readfirstlane(wave) == 0) tile_class = tile_class_of(incl, end - beg);   // (scalar)
         }
         uint32_t incl_px = my_px;
         if constexpr (either) incl_px = wave_incl_sum(my_px);
@@ -1930,6 +1968,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
                     }
 #endif
                     owner_path32<CLEAR>(c, nrec);
+                    if (tid == 0) count_tile_class(L, tile_class);
                     return;
                 }
                 if (base == beg && !keys_early) {
@@ -1980,6 +2019,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
 
     CR_STAMP(2);
     resolve_tile<TS, CLEAR>(c, slotted);
+    if constexpr (TS == 32) if (tid == 0) count_tile_class(L, tile_class);
     CR_STAMP(3);
 #ifdef CRENDER_STAMPS
     if (g_stamps && threadIdx.x == 0) g_stamps[stamp_base + 11] = __builtin_amdgcn_s_memtime();
@@ -2245,6 +2285,10 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     tl.usage_seq = (uint32_t)plan->ticket ^ plan->usage_salt;
     tl.stats = TS == 32 ? plan->stats((int)(plan->ticket & 1u)) : nullptr;
     tl.stats_prev = TS == 32 ? plan->stats((int)((plan->ticket & 1u) ^ 1u)) : nullptr;
+#ifdef CRENDER_NO_STATS          // (experiment builds: 1 = no counting at all, 2 = counting but nobody reads the sums)
+    if (CRENDER_NO_STATS == 1) tl.stats = nullptr;
+    tl.stats_prev = nullptr;
+#endif
     tl.path = (uint32_t)path;
     const unsigned grid = (unsigned)(G.ntiles + tl.nhelp + (ordered ? 1 : 0));
     plan->awaiting[par ^ 1] = false;     // zeroed by this launch

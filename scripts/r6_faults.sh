@@ -7,10 +7,10 @@ cd ${GRAFT_REPO_ROOT:-.}
 OUT=gpurun_out/${OUTDIR:-r6c}; mkdir -p $OUT
 for f in 1 2; do
   export CRENDER_LIB=$(pwd)/scripts/ab/fault$f.so
-  CRENDER_RASTER_PATH=0 timeout -k 10 600 python -m pytest tests/test_hip_parity_gpu.py -m gpu -q -x \
+  CRENDER_RASTER_PATH=0 timeout -k 10 600 python -m pytest tests/test_hip_parity_gpu.py -m gpu -q \
      -k "test_dispatch_order_hint_never_changes_pixels or test_lone_chain_through_changing_scenes or test_fuzz_many_frames_on_the_same_plans" \
      > $OUT/pytest_fault$f.log 2>&1
   echo "fault $f: rc=$? $(tail -1 $OUT/pytest_fault$f.log)"
-  grep -m3 "plan state\|AssertionError" $OUT/pytest_fault$f.log | cut -c1-400
+  grep -E "^FAILED|^E .*plan state" $OUT/pytest_fault$f.log | cut -c1-420 | head -12
 done
 unset CRENDER_LIB

@@ -5,9 +5,9 @@ cd ${GRAFT_REPO_ROOT:-.}
 OUT=gpurun_out/${OUTDIR:-r6a}; mkdir -p $OUT
 for p in ${PATHS:-auto 1 0}; do
   if [ $p = auto ]; then unset CRENDER_RASTER_PATH; else export CRENDER_RASTER_PATH=$p; fi
-  timeout -k 10 900 python -m pytest tests -m gpu -q -x > $OUT/pytest_path_$p.log 2>&1; rc=$?
+  timeout -k 10 900 python -m pytest tests -m gpu -q > $OUT/pytest_path_$p.log 2>&1; rc=$?
   echo "pytest path=$p rc=$rc: $(tail -1 $OUT/pytest_path_$p.log)"
-  [ $rc -ne 0 ] && [ -z "${KEEP_GOING:-}" ] && exit 1
+  [ $rc -ne 0 ] && grep -E "^FAILED|^E  " $OUT/pytest_path_$p.log | cut -c1-300 | head -20
 done
 unset CRENDER_RASTER_PATH
 line() { python -c "

@@ -2660,6 +2660,8 @@ def test_plans_pick_their_raster_kernel_from_what_their_frames_count(hip, oracle
     the launch before it).  bunny 2048^2 — 7 triangles per tile, but large ones — starts on the general kernel
     and moves to the pixel owners with its third frame; T-Rex 1024^2 on 32-pixel tiles stays; the cube (12
     triangles) starts with the owners.  Whatever the kernel, the pixels are the oracle's."""
+    if os.environ.get("CRENDER_RASTER_PATH"):
+        pytest.skip("the suite is being run with one kernel for every plan (CRENDER_RASTER_PATH)")
     for fixture, res, want in (("bunny_inputs.npz", 2048, [0, 0, 1, 1]), ("trex_inputs.npz", 1024, [0, 0, 0, 0]),
                                ("cube_inputs.npz", 256, [1, 1, 1, 1])):
         tri, col, nrm = scene(fixture)
@@ -2688,7 +2690,11 @@ def test_plans_pick_their_raster_kernel_from_what_their_frames_count(hip, oracle
 
 def test_a_swap_chain_shares_what_one_plan_learnt(oracle):
     """The plans of a swap chain (two per slot with look-ahead) render the same stream of frames: the size class one
-    of them has read from its records is every plan's from its next launch on (crender_pipeline_frame)."""
+    of them has read from its records is every plan's from its next launch on (crender_pipeline_frame).  (A plan
+    learns with its third launch: its second launch's record carries what its first counted.  Six plans take
+    turns: the first of them knows at the chain's thirteenth frame, all of them one round later.)"""
+    if os.environ.get("CRENDER_RASTER_PATH"):
+        pytest.skip("the suite is being run with one kernel for every plan (CRENDER_RASTER_PATH)")
     from cython3dmodelrenderer_amd.pixel_buffer_filler import AdvancedPixelBufferFiller
     tri, col, nrm = scene("bunny_inputs.npz")
     res = 2048
@@ -2696,7 +2702,7 @@ def test_a_swap_chain_shares_what_one_plan_learnt(oracle):
     filler = AdvancedPixelBufferFiller(res, res, fov=45.0, pipeline=True, pipeline_depth=3, track_winner=True)
     filler.render_arrays(tri, col, nrm, clear=True)
     filler.synchronize()
-    for k in range(14):
+    for k in range(27):
         filler.render_frame()
         if k % 3 == 2:
             filler.synchronize()
