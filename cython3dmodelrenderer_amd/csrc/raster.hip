@@ -802,9 +802,8 @@ constexpr size_t raster_queue_bytes()
 // Which tile workgroup `b` of a raster launch takes, and which part of it; false: the workgroup is done
 // (it built the dispatch order, found its helper slot empty, or cleared its group of empty tiles).
 template <int TS, bool CLEAR>
-CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad, bool &helper_out, bool &likely_out)
+CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad, bool &helper_out)
 {
-    likely_out = false;      // the tile surely (a helper's) or probably (the order's covered section) has records
     const TileLists &L = c.L;
     const Geom &G = c.G;
     float *const zb = c.zb, *const cb = c.cb, *const nb = c.nb;
@@ -861,7 +860,6 @@ CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad
         if (v == 0) return false;                        // (same word for every thread: uniform)
         tile = (int)v - 1;
         quad = 1 + b % 3;
-        likely_out = true;
     } else {
         const int m = b < lead ? b : b - used;
         if (m == 0 && tid == 0) {
@@ -892,7 +890,6 @@ CR_DEV bool pick_tile(const Tile<TS> &c, int b, int &b_out, int &tile, int &quad
             const int ns = (int)L.hint[1], ng = (int)L.hint[2];
             if (m < ns) {
                 tile = (int)L.order[m];
-                likely_out = true;
             } else {
                 // the order's last section: up to kGroup empty tiles per workgroup, cleared with two
                 // float4 stores per thread and tile (no list to look at: the binning pass vouches
@@ -1707,8 +1704,8 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     // ---- which tile, and which part of it (grid = [order builder, if ordered][3 * hmax helpers][ntiles
     // main workgroups, one tile each])
     int tile, quad;
-    bool helper, likely;
-    if (!pick_tile<TS, CLEAR>(c, b, b, tile, quad, helper, likely)) return;
+    bool helper;
+    if (!pick_tile<TS, CLEAR>(c, b, b, tile, quad, helper)) return;
     const int ty = G.ntx_magic ? (int)__umulhi((uint32_t)tile, G.ntx_magic) : tile / G.ntx;
     const int tx = tile - ty * G.ntx;
     int X0 = tx * TS, Y0 = G.y0 + ty * TS;
@@ -1721,22 +1718,6 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
         g_stamps[stamp_base + 7] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // XCC_ID
         g_stamps[stamp_base + 8] = (unsigned long long)tile;
         g_stamps[stamp_base + 10] = __builtin_amdgcn_s_memtime();
-    }
-#endif
-    // Small frames rendered alone (ordered launches on 32-pixel direct-bin plans): a workgroup whose tile the
-    // previous frame's order lists as covered — or a helper, whose tile THIS frame's binning registered — asks
-    // for its slot's entry of the first batch TOGETHER with the list length instead of after it: one dependent
-    // round trip (~0.7-1 us of a quadrant's 8.6, profiles/r05/stamps_kframe32_trex1024.txt) off the chain.
-    // What the slab holds beyond the list is an older frame's entry: loaded, never used.
-    [[maybe_unused]] float4 se0{}, se1{}, se2{};
-    [[maybe_unused]] bool spec = false;
-#ifndef CRENDER_NO_SPEC_LOADS
-    if constexpr (TS == 32 && PATH == kPathGeneral) {
-        spec = likely && !L.offs && !L.pairs && L.capacity >= (uint32_t)kThreads;
-        if (spec) {
-            const float4 *e = L.bins + ((size_t)tile * L.capacity + (size_t)tid) * 3;
-            se0 = e[0]; se1 = e[1]; se2 = e[2];
-        }
     }
 #endif
     // the tile's triangle list: a run of the scanned index array, or (direct bins, offs == null)
@@ -1819,15 +1800,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     uint32_t cur_id = 0, cur_bx = 0, cur_by = 0;
     TriXYZ cur_t{};
     bool cur_ok = tid < kBatch && beg + tid < end;
-    if (spec) {
-        // (load_record's direct-bin branch on the entry asked for above)
-        cur_t = TriXYZ{se0.x, se0.y, se0.z, se0.w, se1.x, se1.y, se1.z, se1.w, se2.x};
-        cur_id = __float_as_uint(se2.y);
-        cur_bx = __float_as_uint(se2.z);
-        cur_by = __float_as_uint(se2.w);
-        cur_ok = cur_ok && cur_id < L.T;
-        if (cur_ok && L.orig_of) cur_id = L.orig_of[cur_id];
-    } else if (cur_ok) cur_ok = load_record(L, proj, G, beg + tid, cur_id, cur_t, cur_bx, cur_by);
+    if (cur_ok) cur_ok = load_record(L, proj, G, beg + tid, cur_id, cur_t, cur_bx, cur_by);
 
     c.X0 = X0; c.Y0 = Y0; c.X1 = X1; c.Y1 = Y1; c.rw = rw; c.quad = quad; c.beg = beg; c.end = end;
     // (32-pixel tiles: the keys once it is known that the tile is not the pixel owners', see below)
@@ -2283,12 +2256,11 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     tl.hdr = plan->hdr();
     tl.usage = plan->usage_dev + kUsageWords * uslot;
     tl.usage_seq = (uint32_t)plan->ticket ^ plan->usage_salt;
-    tl.stats = TS == 32 ? plan->stats((int)(plan->ticket & 1u)) : nullptr;
+    // (not on the split launches of small frames rendered alone: a device-scope atomic takes 1.5-2 us to come
+    // back, and the one of the tile that ends such a launch ends it that much later — lone T-Rex 1024^2 16.8
+    // against 15.2 us, profiles/r06/ab_stats_atomics.txt; on a frame of 130 us and more it is noise)
+    tl.stats = TS == 32 && !split ? plan->stats((int)(plan->ticket & 1u)) : nullptr;
     tl.stats_prev = TS == 32 ? plan->stats((int)((plan->ticket & 1u) ^ 1u)) : nullptr;
-#ifdef CRENDER_NO_STATS          // (experiment builds: 1 = no counting at all, 2 = counting but nobody reads the sums)
-    if (CRENDER_NO_STATS == 1) tl.stats = nullptr;
-    tl.stats_prev = nullptr;
-#endif
     tl.path = (uint32_t)path;
     const unsigned grid = (unsigned)(G.ntiles + tl.nhelp + (ordered ? 1 : 0));
     plan->awaiting[par ^ 1] = false;     // zeroed by this launch
