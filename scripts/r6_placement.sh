@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/${OUTDIR:-r6p}; mkdir -p $OUT
-for m in torch arena late reuse torch; do
+for m in ${MODES:-torch arena late reuse torch}; do
   timeout -k 10 200 python scripts/placement_probe.py $m 4 2>/dev/null | tee -a $OUT/placement.txt
 done
 # which counters does this box have?  (translation, write-request stalls)
@@ -46,8 +46,11 @@ for k in range(K):
     print(line)
 PY
 }
+if [ -z "${PMC_ONLY:-}" ]; then
 pass utcl1 TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT TCP_UTCL1_REQUEST TCP_UTCL1_PERMISSION_MISS
-pass utcl1_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum
-pass wrreq TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum
-pass wrcredit TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_IO_CREDIT_STALL_sum TCC_EA0_WRREQ_GMI_CREDIT_STALL_sum TCC_EA0_WRREQ_DRAM_sum
-pass tcp TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCC_BUSY_sum TCC_TAG_STALL_sum
+fi
+pass wrreq TCC_EA0_WRREQ TCC_EA0_WRREQ_64B TCC_EA0_WRREQ_STALL TCC_TOO_MANY_EA_WRREQS_STALL
+pass wrdest TCC_EA0_WRREQ_WRITE_DRAM TCC_EA0_WRREQ_WRITE_DRAM_32B TCC_EA0_WRREQ_WRITE_GMI_32B TCC_EA0_WRREQ_WRITE_IO_32B
+pass wrcredit TCC_EA0_WRREQ_DRAM_CREDIT_STALL TCC_EA0_WRREQ_IO_CREDIT_STALL TCC_EA0_WRREQ_GMI_CREDIT_STALL TCC_EA0_WRREQ_DRAM
+pass tcp TCP_TCC_WRITE_REQ TCP_TCC_WRITE_REQ_LATENCY TCP_PENDING_STALL_CYCLES TCC_EA0_WRREQ_LEVEL
+pass tcc TCC_BUSY TCC_TAG_STALL TCC_WRITEBACK TCC_NORMAL_WRITEBACK
