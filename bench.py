@@ -81,9 +81,15 @@ def _profiled(name, workload):
     return doc.get(workload, {})
 
 
-def load_traffic(workload):
-    """HBM bytes per raster launch from the committed PMC profile, if one exists for these kernels."""
-    return _profiled("traffic.json", workload).get("raster_hbm_bytes_per_launch")
+def profile_key(kernel):
+    """'k_frame<32,true,1>' -> 'k_frame_owners': how scripts/summarize_prof.py names the raster kernels."""
+    base = "k_frame" if kernel.startswith("k_frame") else "k_raster"
+    return base + ("_owners" if kernel.endswith(",1>") else "")
+
+
+def load_traffic(workload, kernel):
+    """HBM bytes per launch of THIS kernel from the committed PMC profile, if one exists for these sources."""
+    return _profiled("traffic.json", workload).get(profile_key(kernel), {}).get("hbm_bytes_per_launch")
 
 
 def load_rocprof_avg_ms(workload, kernel):
@@ -538,6 +544,29 @@ def main():
                            "(no exchange: the frame is complete in its memory)"}
         del solo
 
+    # ---- strips: and the WEAK-scaling curve of BASELINE.json's metric ("frames/sec, T-Rex.obj 1024x1024 at
+    # 1/2/4/8 GPUs") from the same run: every rank renders K full frames of the headline workload on its own GPU,
+    # no collective (what --mode frames times), between the same barriers; value = world x K / slowest rank.
+    weak = None
+    if strips:
+        w_tri, w_col, w_nrm, (wH, wW), w_fov = scenes.scene("trex1024")
+        wf = AdvancedPixelBufferFiller(wH, wW, fov=w_fov, device=device, pipeline=not args.no_pipeline, raster_path=rpath)
+        wf.render_arrays(w_tri, w_col, w_nrm, clear=True)
+        wf.synchronize()
+        for _ in range(max(3, args.warmup)):
+            wf.render_frame()
+        wf.synchronize()
+        barrier()
+        t6 = time.perf_counter()
+        for _ in range(args.steps):
+            wf.render_frame()
+        wf.join()
+        barrier()
+        weak_elapsed = time.perf_counter() - t6
+        assert not (wf._pipe is not None and wf._pipe.overflowed(wf))
+        del wf
+        weak = weak_elapsed
+
     # CPUs the thread that submits the frames may run on, NOW (after torch / libgomp are loaded): a
     # runtime that bound it would show here — smallest over the ranks
     try:
@@ -546,10 +575,12 @@ def main():
         affinity = os.cpu_count() or 1
     if world > 1:
         t = torch.tensor([elapsed, raster_ms, bin_ms, elapsed_render_only or 0.0, kframe_events_ms or 0.0,
-                          kframe_b2b_ms or 0.0, -float(affinity)], dtype=torch.float64,
+                          kframe_b2b_ms or 0.0, -float(affinity), weak or 0.0], dtype=torch.float64,
                          device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, raster_ms, bin_ms, ero, ke, kb, naff = (float(v) for v in t.cpu())
+        elapsed, raster_ms, bin_ms, ero, ke, kb, naff, weak_max = (float(v) for v in t.cpu())
+        if weak is not None:
+            weak = weak_max
         affinity = int(-naff)
         if elapsed_render_only is not None:
             elapsed_render_only = ero
@@ -578,12 +609,12 @@ def main():
         if lookahead:
             kernel = f"k_frame<{ts},true,{kpath}>"
             views = {"hip_events_around_each_launch": kframe_events_ms, "frames_back_to_back_on_one_stream": kframe_b2b_ms}
-            prof = load_rocprof_avg_ms(args.workload, "k_frame_one_stream") if rows == H else None
+            prof = load_rocprof_avg_ms(args.workload, profile_key(kernel) + "_one_stream") if rows == H else None
         else:
             kernel = f"k_raster<{ts},true,{kpath}>"
             views = {"hip_events_around_each_launch": raster_ms,
                      "single_stream_frame_minus_event_measured_bin_passes": raster_b2b_ms}
-            prof = load_rocprof_avg_ms(args.workload, "k_raster") if rows == H else None
+            prof = load_rocprof_avg_ms(args.workload, profile_key(kernel)) if rows == H else None
         if prof is not None:
             views["committed_rocprofv3_average"] = prof
         launch_ms = max(v for v in views.values() if v is not None)
@@ -643,7 +674,7 @@ def main():
                          "overlapped_frames_gbps": abytes * (args.steps / elapsed) / 1e9,
                          # PMC bytes of the committed profile are per WHOLE-frame launch: a strip's
                          # launch was not profiled
-                         "traffic": load_traffic(args.workload) if rows == H else None},
+                         "traffic": load_traffic(args.workload, kernel) if rows == H else None},
             "bin_entries": {"needed": need, "capacity": cap},
             # the kernels' sources; profiles/*.json figures are quoted only if they were measured on these
             "csrc_sha16": csrc_sha16(),
@@ -669,6 +700,13 @@ def main():
             out["config"]["multi_gpu"] += ("; predicted by DESIGN.md section 5 to be SLOWER than one GPU with exchange = "
                                            "planes (the exchange, not the rasterization, bounds the sharded frame)"
                                            if args.exchange == "planes" and gathered else "")
+        if weak is not None:
+            out["weak_scaling_frames"] = {
+                "metric": "frames/sec", "workload": "trex1024", "n_gpus": world, "scaling": "weak",
+                "value": world * args.steps / weak, "ms_per_step": weak / args.steps * 1e3, "steps": args.steps,
+                "what": "measured in this same run after the strips: every rank K full frames of BASELINE.json's "
+                        "headline workload on its own GPU, no collective (bench.py --mode frames), barrier to barrier, "
+                        "slowest rank; divide by the N = 1 line's value for the weak-scaling efficiency"}
         if one_gpu is not None:
             one_gpu["speedup_of_this_line"] = fps / one_gpu["value"]
             out["strong_scaling_reference"] = one_gpu

@@ -71,8 +71,11 @@ bool make_layout(int H, int W, int y0, int y1, int64_t max_T, int64_t cap, int t
 #define CRENDER_PAIR_MULT 3
 #endif
         int64_t pc = (CRENDER_PAIR_MULT * max_T / L.g.ntiles + 64 + 63) / 64 * 64;
+        // (a scene whose MEAN list — 1.3 entries per triangle — already fills the clamped slab would overflow
+        // it on its first frame and leave up to 2 GB allocated and dead: such plans get no slabs at all)
+        const bool hopeless = pc > 8192 && 13 * max_T / 10 / L.g.ntiles > 8192;
         if (pc > 8192) pc = 8192;
-        if (pc * (int64_t)sizeof(uint2) * L.g.ntiles <= kPairBinBytes) L.pair_cap = pc;
+        if (!hopeless && pc * (int64_t)sizeof(uint2) * L.g.ntiles <= kPairBinBytes) L.pair_cap = pc;
     }
     // heavy tiles are split with direct bins only (the small-frame regime, where a single tile's
     // latency sets the end of the launch): on 16-pixel tiles and — for frames rendered alone on the

@@ -21,21 +21,24 @@ for wl in ("trex1024", "bunny4096", "trex8192", "synth10m", "cube256"):
     e = {}
     for f in glob.glob(os.path.join(root, f"prof_{wl}", "trace", "**", "*kernel_trace.csv"), recursive=True):
         r = split_by_overlap(f, quiet=True)
-        if "k_raster" in r:
-            v = r["k_raster"][0] + r["k_raster"][1]
-            e["k_raster"] = sum(v) / len(v)
-            e["k_raster_calls"] = len(v)
+        for key in ("k_raster", "k_raster_owners"):          # (general kernel / pixel owners' kernel: csrc/raster.hip kPath*)
+            if key in r:
+                v = r[key][0] + r[key][1]
+                e[key] = sum(v) / len(v)
+                e[key + "_calls"] = len(v)
     for f in glob.glob(os.path.join(root, f"prof_{wl}_pipelined", "trace", "**", "*kernel_trace.csv"), recursive=True):
         r = split_by_overlap(f, quiet=True)
-        if "k_frame" in r:
-            alone, over, scratch = r["k_frame"]
+        for key in ("k_frame", "k_frame_owners"):
+            if key not in r:
+                continue
+            alone, over, scratch = r[key]
             if alone:
-                e["k_frame_one_stream"] = sum(alone) / len(alone)
-                e["k_frame_one_stream_calls"] = len(alone)
+                e[key + "_one_stream"] = sum(alone) / len(alone)
+                e[key + "_one_stream_calls"] = len(alone)
             if over:
-                e["k_frame_overlapped"] = sum(over) / len(over)
-                e["k_frame_overlapped_calls"] = len(over)
-            e["k_frame_scratch_bytes"] = scratch
+                e[key + "_overlapped"] = sum(over) / len(over)
+                e[key + "_overlapped_calls"] = len(over)
+            e[key + "_scratch_bytes"] = scratch
     if e:
         e["source"] = "rocprofv3 --kernel-trace --stats of bench.py (scripts/profile_gpu.sh), ns"
         out[wl] = e

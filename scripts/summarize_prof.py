@@ -6,6 +6,7 @@ wide reads, MI355X_MICROARCH.md "HBM")."""
 import csv
 import glob
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -14,6 +15,9 @@ def short(name):
     for k in ("k_raster", "k_frame", "k_setup", "k_bin_wave", "k_count_wave", "k_scan", "k_fill", "k_project", "k_clear", "k_keys_init",
               "k_cover_atomic", "k_resolve_global", "k_guro"):
         if k in name:
+            # (32-pixel plans have two raster kernels, csrc/raster.hip kPath*: <TS, CLEAR, 1> is the pixel owners')
+            if k in ("k_raster", "k_frame") and re.search(k + r"<\d+, *(true|false), *1>", name):
+                return k + "_owners"
             return k
     return name[:40]
 

@@ -2570,6 +2570,9 @@ def test_bench_launch_contract_two_ranks_strips():
                                                        "present": 3 * 4096 * 8192}
     assert abs(ex["exchange_ms"] - (d["ms_per_step"] - d["ms_per_step_without_exchange"])) < 1e-9
     assert "speedup_lone_frame" in d and d["csrc_sha16"]
+    wk = d["weak_scaling_frames"]                           # and the weak-scaling curve's point from the same run
+    assert wk["workload"] == "trex1024" and wk["n_gpus"] == 2 and wk["scaling"] == "weak" and wk["value"] > 0
+    assert d["config"]["raster_path"]["asked"] == "auto"
 
 
 @pytest.mark.gpu

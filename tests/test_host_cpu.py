@@ -404,14 +404,18 @@ def test_profile_figures_are_quoted_only_for_the_sources_they_were_measured_on(t
     prof.mkdir()
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     for stamp, want in ((sha, True), ("0" * 16, False), (None, False)):
-        doc_t = {"trex1024": {"raster_hbm_bytes_per_launch": 123.0}}
-        doc_k = {"trex1024": {"k_raster": 11000.0}}
+        doc_t = {"trex1024": {"k_raster": {"hbm_bytes_per_launch": 123.0}, "k_frame_owners": {"hbm_bytes_per_launch": 456.0}}}
+        doc_k = {"trex1024": {"k_raster": 11000.0, "k_frame_owners_one_stream": 13000.0}}
         if stamp is not None:
             doc_t["csrc_sha16"] = doc_k["csrc_sha16"] = stamp
         (prof / "traffic.json").write_text(json.dumps(doc_t))
         (prof / "kernel_avg.json").write_text(json.dumps(doc_k))
-        assert bench.load_traffic("trex1024") == (123.0 if want else None)
-        assert bench.load_rocprof_avg_ms("trex1024", "k_raster") == (0.011 if want else None)
+        # (each raster kernel has its own figures: a line quotes those of ITS roofline.kernel)
+        assert bench.load_traffic("trex1024", "k_raster<16,true,0>") == (123.0 if want else None)
+        assert bench.load_traffic("trex1024", "k_frame<32,true,1>") == (456.0 if want else None)
+        assert bench.load_traffic("trex1024", "k_frame<32,true,0>") is None
+        assert bench.load_rocprof_avg_ms("trex1024", bench.profile_key("k_raster<32,true,0>")) == (0.011 if want else None)
+        assert bench.load_rocprof_avg_ms("trex1024", bench.profile_key("k_frame<32,true,1>") + "_one_stream") == (0.013 if want else None)
     # the fingerprint follows the sources: one more byte in a translation unit changes it
     monkeypatch.setattr(_build, "HIPCC_FLAGS", _build.HIPCC_FLAGS + ["-DX"])
     assert _build.source_sha16() != sha
