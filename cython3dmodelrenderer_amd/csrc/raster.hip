@@ -1300,8 +1300,13 @@ CR_DEV int owners_queue(const Tile<32> &c, uint32_t base, bool first)
     return tile_class;
 }
 
-// A list of more than one batch (rare where this kernel is chosen; this path may spill, the one-batch
-// path — owner_tile — must not): the pixels' running minimum keys stay in registers across the batches.
+// A list of more than one batch (rare where this kernel is chosen).  The one-batch path's register budget is
+// spent on a thread's FOUR pixels; carried across batches as well, the same state spilled (and a kernel with
+// scratch is slower for every workgroup, whether it takes the spilling path or not: the general kernel lost
+// 12 % of the swap chain's frames to 48 bytes of it, profiles/r06/ab_compaction.txt).  So a long list is walked
+// FOUR times, once per pixel of the thread, with that pixel's running minimum key in registers across the
+// batches; each batch stores the pixel if it won it (a later batch's winner writes it again: same thread,
+// program order), the background last.  Four times the record loads, on tiles that are rare here by choice.
 template <bool CLEAR, typename I>
 CR_DEV void owners_batches(const Tile<32> &c)
 {
@@ -1310,130 +1315,102 @@ CR_DEV void owners_batches(const Tile<32> &c)
     OwnerQueue &oq = *reinterpret_cast<OwnerQueue *>(qraw);
     float *pre = reinterpret_cast<float *>(key);
     constexpr int XS = 8;
-    const int Xs = X0 + (tid & 7), Y = Y0 + (tid >> 3);
-    const bool mine_in = Y < Y1 && Xs < X1;
-    const I pix0 = (I)((I)Y * (I)G.W + (I)Xs);
-    unsigned long long best[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        best[j] = make_key(zord(1e6f), KEY_LOW_PRIOR);
-        if (!CLEAR && Y < Y1 && Xs + XS * j < X1) best[j] = make_key(zord_prior(*elem(zb, (I)(pix0 + XS * j))), KEY_LOW_PRIOR);
-    }
+    const int Y = Y0 + (tid >> 3);
     const uint32_t my_band = 1u << (tid >> 6);
     int tile_class = -1;
-    for (uint32_t base = beg; base < end; base += kThreads) {
-        const int cls = owners_queue(c, base, base == beg);
-        if (base == beg) tile_class = cls;
-        if (base == beg) CR_STAMP(6);
-        const int nrec = (int)((end - base) < (uint32_t)kThreads ? (end - base) : (uint32_t)kThreads);
-        // ---- the owners walk the batch (owner_tile's loop) ---------------------------------------------
-        float w1[4], w2[4], w3[4];          // the barycentrics of the pixels this batch wins
-        uint32_t slots = 0, won = 0;        // their record slots, one byte per pixel; which of the four
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w1[j] = w2[j] = w3[j] = 0.0f;
-        for (int r = 0; r < nrec; ++r) {
-            const float4 p0 = *reinterpret_cast<const float4 *>(pre + 8 * r);
-            const uint32_t flags = __float_as_uint(p0.w);
-            if (!(flags & my_band)) continue;           // (uniform over the wavefront)
-            const uint32_t pb = oq.box[r];
-            const uint32_t wh = packed_wh(pb), xy = packed_xy(pb, X0, Y0);
-            const int bx0 = (int)(xy & 0xFFFF), by0 = (int)(xy >> 16);
-            const int bx1 = bx0 + box_w(wh), by1 = by0 + box_h(wh);
-            TriSetup st;
-            {
-                const float4 p1 = *reinterpret_cast<const float4 *>(pre + 8 * r + 4);
-                st.x0 = oq.x0[r]; st.y0 = oq.y0[r]; st.z0 = oq.z0[r];
-                st.x1 = oq.x1[r]; st.y1 = oq.y1[r]; st.z1 = oq.z1[r];
-                st.x2 = oq.x2[r]; st.y2 = oq.y2[r]; st.z2 = oq.z2[r];
-                st.l01 = st.x1 - st.x2; st.l02 = st.y1 - st.y2;
-                st.l11 = st.x2 - st.x0; st.l12 = st.y2 - st.y0;
-                st.l21 = st.x0 - st.x1; st.l22 = st.y0 - st.y1;
-                st.l03 = p0.x; st.l13 = p0.y; st.l23 = p0.z; st.fast = (flags & kOwnFast) != 0;
-                st.r1 = p1.x; st.r2 = p1.y; st.r3 = p1.z;
-                auto sign_of = [](uint32_t two_bits) { return two_bits == 1u ? 1.0f : two_bits == 2u ? -1.0f : 0.0f; };
-                st.rej1 = sign_of((flags >> 5) & 3u); st.rej2 = sign_of((flags >> 7) & 3u); st.rej3 = sign_of((flags >> 9) & 3u);
-            }
-            const uint32_t low = 0xFFFFFFFEu - oq.tri[r];
-            const bool rows_ok = Y >= by0 && Y < by1;
-            const float fy = (float)Y;
-            const float ry1 = st.l01 * (fy - st.y2), ry2 = st.l11 * (fy - st.y0), ry3 = st.l21 * (fy - st.y1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        const int x = X0 + (tid & 7) + XS * j;
+        const bool mine_in = Y < Y1 && x < X1;
+        const I pix = (I)((I)Y * (I)G.W + (I)x);
+        unsigned long long best = make_key(zord(1e6f), KEY_LOW_PRIOR);
+        if (!CLEAR && mine_in) best = make_key(zord_prior(*elem(zb, pix)), KEY_LOW_PRIOR);
+        const float fx = (float)x, fy = (float)Y;
+#pragma unroll 1
+        for (uint32_t base = beg; base < end; base += kThreads) {
+            const int cls = owners_queue(c, base, j == 0 && base == beg);
+            if (j == 0 && base == beg) tile_class = cls;
+            const int nrec = (int)((end - base) < (uint32_t)kThreads ? (end - base) : (uint32_t)kThreads);
+            float w1 = 0.0f, w2 = 0.0f, w3 = 0.0f;
+            int slot = -1;                  // the record of this batch that wins the pixel, if any
+            for (int r = 0; r < nrec; ++r) {
+                const float4 p0 = *reinterpret_cast<const float4 *>(pre + 8 * r);
+                const uint32_t flags = __float_as_uint(p0.w);
+                if (!(flags & my_band)) continue;           // (uniform over the wavefront)
+                const uint32_t pb = oq.box[r];
+                const uint32_t wh = packed_wh(pb), xy = packed_xy(pb, X0, Y0);
+                const int bx0 = (int)(xy & 0xFFFF), by0 = (int)(xy >> 16);
+                const int bx1 = bx0 + box_w(wh), by1 = by0 + box_h(wh);
                 if (X0 + XS * j >= bx1 || X0 + XS * j + XS <= bx0) continue;     // the box misses block j (uniform)
-                const int x = Xs + XS * j;
-                const float fx = (float)x;
-                const float n1 = ry1 - st.l02 * (fx - st.x2), n2 = ry2 - st.l12 * (fx - st.x0), n3 = ry3 - st.l22 * (fx - st.x1);
-                const bool live = rows_ok && (unsigned)(x - bx0) < (unsigned)(bx1 - bx0) && !surely_outside(st, n1, n2, n3);
-                if (wave_any(live)) {
-                    if (live) {
-                        float b1, b2, b3;
-                        quotients(st, n1, n2, n3, true, b1, b2, b3);
-                        if (!(b1 < 0.0f || b2 < 0.0f || b3 < 0.0f)) {          // .pyx:215-216 (NaN passes)
-                            const float z = interp(st.z0, st.z1, st.z2, b1, b2, b3);
-                            if (z == z) {                                      // .pyx:220
-                                const unsigned long long k = make_key(zord(z), low);
-                                if (k < best[j]) {
-                                    best[j] = k;
-                                    w1[j] = b1; w2[j] = b2; w3[j] = b3;
-                                    slots = (slots & ~(0xFFu << (8 * j))) | ((uint32_t)r << (8 * j));
-                                    won |= 1u << j;
-                                }
+                TriSetup st;
+                {
+                    const float4 p1 = *reinterpret_cast<const float4 *>(pre + 8 * r + 4);
+                    st.x0 = oq.x0[r]; st.y0 = oq.y0[r]; st.z0 = oq.z0[r];
+                    st.x1 = oq.x1[r]; st.y1 = oq.y1[r]; st.z1 = oq.z1[r];
+                    st.x2 = oq.x2[r]; st.y2 = oq.y2[r]; st.z2 = oq.z2[r];
+                    st.l01 = st.x1 - st.x2; st.l02 = st.y1 - st.y2;
+                    st.l11 = st.x2 - st.x0; st.l12 = st.y2 - st.y0;
+                    st.l21 = st.x0 - st.x1; st.l22 = st.y0 - st.y1;
+                    st.l03 = p0.x; st.l13 = p0.y; st.l23 = p0.z; st.fast = (flags & kOwnFast) != 0;
+                    st.r1 = p1.x; st.r2 = p1.y; st.r3 = p1.z;
+                    auto sign_of = [](uint32_t two_bits) { return two_bits == 1u ? 1.0f : two_bits == 2u ? -1.0f : 0.0f; };
+                    st.rej1 = sign_of((flags >> 5) & 3u); st.rej2 = sign_of((flags >> 7) & 3u); st.rej3 = sign_of((flags >> 9) & 3u);
+                }
+                // numerators() (mu.pyx:34 before the division), the operations in the reference's order
+                const float n1 = st.l01 * (fy - st.y2) - st.l02 * (fx - st.x2);
+                const float n2 = st.l11 * (fy - st.y0) - st.l12 * (fx - st.x0);
+                const float n3 = st.l21 * (fy - st.y1) - st.l22 * (fx - st.x1);
+                const bool live = Y >= by0 && Y < by1 && (unsigned)(x - bx0) < (unsigned)(bx1 - bx0) &&
+                                  !surely_outside(st, n1, n2, n3);
+                if (!wave_any(live)) continue;
+                if (live) {
+                    float b1, b2, b3;
+                    quotients(st, n1, n2, n3, true, b1, b2, b3);
+                    if (!(b1 < 0.0f || b2 < 0.0f || b3 < 0.0f)) {          // .pyx:215-216 (NaN passes)
+                        const float z = interp(st.z0, st.z1, st.z2, b1, b2, b3);
+                        if (z == z) {                                      // .pyx:220
+                            const unsigned long long k = make_key(zord(z), 0xFFFFFFFEu - oq.tri[r]);
+                            if (k < best) {
+                                best = k;
+                                w1 = b1; w2 = b2; w3 = b3;
+                                slot = r;
                             }
                         }
                     }
                 }
             }
-        }
-        // ---- the pixels this batch won: interpolate and store (.pyx:219, 226-242) ----------------------
-        if (mine_in && won) {
-            float *zp = elem(zb, pix0), *cp = elem(cb, (I)(pix0 * 3)), *np_ = elem(nb, (I)(pix0 * 3));
-            int32_t *wp = win ? reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix0)) : nullptr;
-            uint32_t prev = 0xFFFFFFFFu, tid_w = 0;
-            float cc[9], nn[9], z0 = 0.f, z1 = 0.f, z2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (!((won >> j) & 1u) || Xs + XS * j >= X1) continue;
-                const uint32_t sl = (slots >> (8 * j)) & 0xFFu;
-                if (sl != prev) {            // (a thread's four pixels mostly share their winner)
-                    prev = sl;
-                    tid_w = oq.tri[sl];
-                    z0 = oq.z0[sl]; z1 = oq.z1[sl]; z2 = oq.z2[sl];
-                    const uint32_t at = L.pos_of ? L.pos_of[tid_w] : tid_w;
-                    load9(elem(col, (I)((I)at * 9)), cc);
-                    load9(elem(nrm, (I)((I)at * 9)), nn);
-                }
-                const float b1 = w1[j], b2 = w2[j], b3 = w3[j];
-                const float zv = interp(z0, z1, z2, b1, b2, b3);
-                float c0 = interp(cc[0], cc[3], cc[6], b1, b2, b3);
-                float c1 = interp(cc[1], cc[4], cc[7], b1, b2, b3);
-                float c2 = interp(cc[2], cc[5], cc[8], b1, b2, b3);
-                const float n0 = interp(nn[0], nn[3], nn[6], b1, b2, b3);
-                const float n1 = interp(nn[1], nn[4], nn[7], b1, b2, b3);
-                const float n2 = interp(nn[2], nn[5], nn[8], b1, b2, b3);
+            // ---- the pixel, if this batch won it: interpolate and store (.pyx:219, 226-242) ----------------
+            if (mine_in && slot >= 0) {
+                const uint32_t tid_w = oq.tri[slot];
+                const uint32_t at = L.pos_of ? L.pos_of[tid_w] : tid_w;
+                float cc[9], nn[9];
+                load9(elem(col, (I)((I)at * 9)), cc);
+                load9(elem(nrm, (I)((I)at * 9)), nn);
+                const float zv = interp(oq.z0[slot], oq.z1[slot], oq.z2[slot], w1, w2, w3);
+                float c0 = interp(cc[0], cc[3], cc[6], w1, w2, w3);
+                float c1 = interp(cc[1], cc[4], cc[7], w1, w2, w3);
+                float c2 = interp(cc[2], cc[5], cc[8], w1, w2, w3);
+                const float n0 = interp(nn[0], nn[3], nn[6], w1, w2, w3);
+                const float n1 = interp(nn[1], nn[4], nn[7], w1, w2, w3);
+                const float n2 = interp(nn[2], nn[5], nn[8], w1, w2, w3);
                 if (L.light.on) {
                     const float f = guro_factor(L.light, n0, n1, n2);
                     c0 *= f; c1 *= f; c2 *= f;
                 }
-                const int o = XS * j;
-                zp[o] = zv;
-                cp[3 * o] = c0; cp[3 * o + 1] = c1; cp[3 * o + 2] = c2;
-                np_[3 * o] = n0; np_[3 * o + 1] = n1; np_[3 * o + 2] = n2;
-                if (wp) wp[o] = (int32_t)tid_w;
+                *elem(zb, pix) = zv;
+                float *cp = elem(cb, (I)(pix * 3)), *np_ = elem(nb, (I)(pix * 3));
+                cp[0] = c0; cp[1] = c1; cp[2] = c2;
+                np_[0] = n0; np_[1] = n1; np_[2] = n2;
+                if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = (int32_t)tid_w;
             }
         }
-    }
-    // ---- background: the pixels no batch won (fused clear) ---------------------------------------------
-    if (CLEAR && mine_in) {
-        float *zp = elem(zb, pix0), *cp = elem(cb, (I)(pix0 * 3)), *np_ = elem(nb, (I)(pix0 * 3));
-        int32_t *wp = win ? reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix0)) : nullptr;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (Xs + XS * j >= X1 || (uint32_t)best[j] != KEY_LOW_PRIOR) continue;
-            const int o = XS * j;
-            zp[o] = 1e6f;
-            cp[3 * o] = 0.0f; cp[3 * o + 1] = 0.0f; cp[3 * o + 2] = 0.0f;
-            np_[3 * o] = 0.0f; np_[3 * o + 1] = 0.0f; np_[3 * o + 2] = 0.0f;
-            if (wp) wp[o] = -1;
+        // ---- background: a pixel no batch won (fused clear) --------------------------------------------
+        if (CLEAR && mine_in && (uint32_t)best == KEY_LOW_PRIOR) {
+            *elem(zb, pix) = 1e6f;
+            float *cp = elem(cb, (I)(pix * 3)), *np_ = elem(nb, (I)(pix * 3));
+            cp[0] = 0.0f; cp[1] = 0.0f; cp[2] = 0.0f;
+            np_[0] = 0.0f; np_[1] = 0.0f; np_[2] = 0.0f;
+            if (win) *reinterpret_cast<int32_t *>(elem(reinterpret_cast<float *>(win), pix)) = -1;
         }
     }
     if (tid == 0) count_tile_class(L, tile_class);
