@@ -433,8 +433,12 @@ int crender_plan_debug_check(crender_plan *plan, void *stream, char *msg, size_t
         for (int i = 0; i < 3 * (L.hmax > 0 ? L.hmax : 1); ++i)
             if (hslots[i]) { if (fs < 0) fs = i; ++nsl; }
         if (nsl) say("%d helper-slot words left set after the raster launch, first slot %d = tile %u", nsl, fs, hslots[fs] - 1);
-    } else if (binned_only && !plan->unrastered[par ^ 1]) {
-        // (B) binned, not rasterized yet: the registrations must match the flags, the slots and the lists
+    } else if (binned_only) {
+        // (B) binned, not rasterized yet: the registrations must match the flags, the slots and the lists —
+        // and the OTHER parity must not hold a binned frame that was never rasterized: a binning pass that finds
+        // one starts the plan over (flags, slots and the order hint exist once, not per parity)
+        if (plan->unrastered[par ^ 1])
+            say("%s", "both parities hold a binned frame that was never rasterized: the binning pass did not start the plan over");
         const bool split = plan->last_frame_direct && L.hmax > 0 && plan->frame_lone;
         const uint32_t at = heavy_at(L.ts);
         if (split) {

@@ -13,13 +13,16 @@ set -u
 WL=${1:-trex1024}; STEPS=${2:-50}; shift 2 || true
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 MODE=${MODE:-single}
-OUT=$REPO/gpurun_out/prof_$WL; [ $MODE = pipelined ] && OUT=$REPO/gpurun_out/prof_${WL}_pipelined
+OUT=$REPO/gpurun_out/prof_$WL${SUFFIX:-}; [ $MODE = pipelined ] && OUT=$REPO/gpurun_out/prof_${WL}_pipelined${SUFFIX:-}
+# (SUFFIX=_general with extra args "--raster-path 0": the same command on the other raster kernel, into a directory of its own;
+#  TRACE_ONLY=1: the kernel trace alone)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 NOPIPE=--no-pipeline; [ $MODE = pipelined ] && NOPIPE=
 ARGS="$REPO/bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline --no-api-calls $NOPIPE $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
+[ -n "${TRACE_ONLY:-}" ] && exit 0
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 $ARGS > "$OUT/pmc_$C.log" 2>&1
   echo "pmc $C rc=$?"

@@ -25,6 +25,12 @@ for w in trex1024 bunny4096 trex8192; do
   python scripts/summarize_prof.py gpurun_out/prof_${w}_pipelined | grep -v "at::native\|rocclr\|^void" > $OUT/rocprof_${w}_pipelined.txt
   cp gpurun_out/prof_${w}_pipelined/trace/*/*kernel_stats.csv $OUT/${w}_pipelined_kernel_stats.csv 2>/dev/null
 done
+# the same box's launches on the OTHER raster kernel, for the workloads whose plans choose the pixel owners (kernel trace only)
+for w in bunny4096 trex8192; do
+  rm -rf gpurun_out/prof_${w}_general
+  SUFFIX=_general TRACE_ONLY=1 scripts/profile_gpu.sh $w 20 --raster-path 0 > $OUT/profile_${w}_general.log 2>&1
+  python scripts/summarize_prof.py gpurun_out/prof_${w}_general | grep -E "^k_raster|^k_frame|^## kernel stats" > $OUT/rocprof_${w}_general_kernel.txt
+done
 python scripts/make_kernel_avg_json.py gpurun_out > $OUT/kernel_avg.log 2>&1
 cp profiles/kernel_avg.json $OUT/kernel_avg.json
 python scripts/make_traffic_json.py $OUT > $OUT/traffic.log 2>&1
