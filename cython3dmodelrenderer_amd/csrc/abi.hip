@@ -416,6 +416,9 @@ int crender_plan_debug_check(crender_plan *plan, void *stream, char *msg, size_t
     const int par = plan->parity;
     const bool binned_only = plan->unrastered[par];          // binned, its raster launch not issued yet
     const bool virgin = plan->frame_no == 0;
+    if (!virgin && !binned_only && plan->unrastered[par ^ 1])
+        say("parity %d holds a binned frame that was never rasterized although a later frame was binned and rasterized: "
+            "that frame's binning pass did not start the plan over", par ^ 1);
     if (!virgin && !plan->unrastered[0] && !plan->unrastered[1]) {
         // (A) the last frame was rasterized: the other parity is ready for the next frame, nothing is handed off
         int nz = 0, first = -1;
