@@ -730,6 +730,16 @@ def test_c_abi_argument_errors(hip):
     ws = torch.empty(1024, dtype=torch.uint8, device="cuda:0")
     assert L.crender_plan_create(C.byref(plan), 64, 64, 0, 64, 1000, 0, 0, ws.data_ptr(), 1024,
                                  None) == _capi.ENOMEM
+    # round 6's entry points: the raster kernel choice and the state check
+    assert L.crender_plan_set_raster_path(None, 0) == _capi.EINVAL
+    assert L.crender_plan_debug_check(None, None, None, 0) == _capi.EINVAL
+    assert L.crender_set_default_raster_path(7) == _capi.EINVAL and b"-1" in L.crender_last_error()
+    p2 = hip.Plan(64, 64, 10, tile=32)
+    assert L.crender_plan_set_raster_path(p2.handle, 2) == _capi.EINVAL
+    assert L.crender_plan_set_raster_path(p2.handle, 1) == _capi.OK and L.crender_plan_last_raster_path(p2.handle) == 0
+    p2.debug_check()                                  # a plan that has rendered nothing is consistent
+    buf = C.create_string_buffer(64)
+    assert L.crender_plan_debug_check(p2.handle, None, buf, 64) == _capi.OK and buf.value == b""
 
 
 def test_fast_division_is_bit_exact(hip):
