@@ -3,6 +3,9 @@
 # CAUSES them?  Two libraries with one defect each compiled back in (scripts/ab/fault1.so: hand-off words not reset
 # when the pixel owners take a split tile, commit 30ca3df's fix removed; fault2.so: a binning discarded by the
 # look-ahead leaves its split flags and helper slots, f924058's fix removed), the tests that found them by pixels.
+# The two libraries are built in the container first (git-ignored, they travel with gpurun):
+#   scripts/dev_build.sh --no-dev-knobs -DCRENDER_FAULT=1 --out scripts/ab/fault1.so
+#   scripts/dev_build.sh --no-dev-knobs -DCRENDER_FAULT=2 --out scripts/ab/fault2.so
 cd ${GRAFT_REPO_ROOT:-.}
 OUT=gpurun_out/${OUTDIR:-r6c}; mkdir -p $OUT
 for f in 1 2; do
