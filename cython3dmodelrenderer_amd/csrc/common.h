@@ -42,7 +42,7 @@ constexpr int kThreads = 256;           // 4 wavefronts per workgroup
 // instantiation fits without spilling, the compositing one spills 4 registers).  The 64-pixel
 // kernel is limited by its 48 KB of LDS, not by registers.  (r01 A/B, same box.)
 constexpr int kWavesPerSimd16 = 7, kWavesPerSimd32 = 6;   // (32-pixel tiles: 28.7 KB of LDS = 5 workgroups per CU)
-// the 32-pixel kernel with the pixel owners alone (raster.hip, kPathOwners): seven wavefronts (72 registers,
+// the 32-pixel kernel with the pixel owners alone (raster.hip, kPathOwners): seven wavefronts (70 registers,
 // 19.5 KB of LDS)
 #ifndef CRENDER_WAVES_OWNERS
 #define CRENDER_WAVES_OWNERS 7

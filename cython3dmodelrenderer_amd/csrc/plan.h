@@ -83,9 +83,10 @@ struct crender_plan {
                                   // CRENDER_OVERLAPPED_FRAMES): ordered dispatch and split heavy tiles
     // Bin-list usage of every frame without a host round trip (crender_plan_poll_bin_usage): each
     // raster launch copies the header words crender_plan_last_bin_usage reads into a record of its
-    // own in PINNED host memory the plan owns — one 16-byte store by one thread of the launch,
-    // {frame number, hdr[0], hdr[1], hdr[4]} — so that the host learns of an overflow by reading its
-    // own memory: no copy command, no event, no synchronisation.  Ring of kUsageRing frames.
+    // own in PINNED host memory the plan owns — two 16-byte stores by one thread of the launch,
+    // {frame number, hdr[0], hdr[1], hdr[4]} {large tiles, small tiles, kernel, frame number} — so that the host
+    // learns of an overflow (and of the frames' size class) by reading its own memory: no copy command, no event,
+    // no synchronisation.  Ring of kUsageRing frames.
     uint32_t *usage = nullptr;            // [kUsageRing + 1][kUsageWords] (the last one: staging of the blocking query)
     uint32_t *usage_dev = nullptr;        // the same memory as the device addresses it
     int usage_slot = -1;                  // its slot in the process-wide pool of pinned records (-1: an allocation of its own)

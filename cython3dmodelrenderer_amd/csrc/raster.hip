@@ -437,8 +437,9 @@ struct TileLists {
     int vec_clear;              // planes 16-byte aligned and W % 4 == 0
     Light light;                // CRENDER_FUSED_GURO: illumination applied as pixels are stored
     // this frame's bin-usage record in the plan's pinned host memory (crender_plan_poll_bin_usage):
-    // {frame number, hdr[0], hdr[1], hdr[4]}, one 16-byte store by the launch's LAST main workgroup
-    // (in raster order a corner tile, in an ordered launch a group of empty tiles: nobody's critical path)
+    // {frame number, hdr[0], hdr[1], hdr[4]} {large tiles, small tiles, kernel, frame number}, two 16-byte stores
+    // by the launch's LAST main workgroup (in raster order a corner tile, in an ordered launch a group of empty
+    // tiles: nobody's critical path)
     const uint32_t *hdr;
     uint32_t *usage;
     uint32_t usage_seq;
@@ -1752,9 +1753,17 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     } else if constexpr (PATH == kPathOwners) {
         c.X0 = X0; c.Y0 = Y0; c.X1 = X1; c.Y1 = Y1; c.rw = rw; c.quad = quad; c.beg = beg; c.end = end;
         CR_STAMP(1);
+#ifdef CRENDER_STAMPS
+        if (g_stamps && tid == 0) {
+            g_stamps[stamp_base + 4] = end - beg;
+            g_stamps[stamp_base + 9] = (unsigned long long)(quad + 1);
+        }
+#endif
         if (end - beg <= (uint32_t)kThreads) {
             const int tile_class = owners_queue(c, beg, true);
             CR_STAMP(6);
+            CR_STAMP(5);
+            CR_STAMP(2);     // (diagnostic builds: "swept" = the queue is built; the record loop and the resolve are one function)
             const OwnerQueue &oq = *reinterpret_cast<const OwnerQueue *>(qraw);
             const float *pre = reinterpret_cast<const float *>(key);
             if (L.addr32)
