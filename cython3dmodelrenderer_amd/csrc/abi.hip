@@ -442,11 +442,12 @@ int crender_plan_debug_check(crender_plan *plan, void *stream, char *msg, size_t
         // one starts the plan over (flags, slots and the order hint exist once, not per parity)
         if (plan->unrastered[par ^ 1])
             say("%s", "both parities hold a binned frame that was never rasterized: the binning pass did not start the plan over");
-        const bool split = plan->last_frame_direct && L.hmax > 0 && plan->frame_lone;
-        const uint32_t at = heavy_at(L.ts);
+        const bool split = plan->last_frame_direct && plan->frame_hmax > 0;
+        const uint32_t at = plan->frame_heavy_at;
         if (split) {
             const uint32_t reg = hdr[2 + par];
-            const uint32_t used = reg < (uint32_t)L.hmax ? reg : (uint32_t)L.hmax;
+            const uint32_t hm = (uint32_t)plan->frame_hmax;
+            const uint32_t used = reg < hm ? reg : hm;
             std::vector<int> slot_of(nt, -1);
             for (uint32_t k = 0; k < (uint32_t)L.hmax; ++k) {
                 const uint32_t a = hslots[3 * k], b = hslots[3 * k + 1], c = hslots[3 * k + 2];

@@ -591,6 +591,19 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
     const int par = (int)(plan->frame_no++ & 1u);
     plan->parity = par;
     plan->frame_lone = !(flags & CRENDER_OVERLAPPED_FRAMES) || (dbg & 16384);
+    // Which lists are split among several workgroups (binning.h, "heavy tiles"): on a frame rendered alone the
+    // plan's own thresholds (32-pixel plans of small frames: every covered tile, in quadrants); on a frame of a
+    // swap chain — whose tiles are one workgroup each — only the long ones, from 32 records in halves and from 64
+    // in quadrants, at most kMaxHeavyHelped of them: a frame in flight whose longest tiles are shared out ends
+    // sooner when it runs with few others (the fill and drain of a burst), and costs the steady state nothing
+    // (T-Rex 1024^2: +2.7 % at the driver's 20 steps, +1.9 % at 200; profiles/r06/ab_split_overlapped.txt).
+    plan->frame_hmax = 0;
+    plan->frame_heavy_at = plan->frame_quad_at = 0;
+    if (direct && L.hmax > 0 && !(dbg & 2048)) {
+        plan->frame_hmax = plan->frame_lone || L.hmax < kMaxHeavyHelped ? L.hmax : kMaxHeavyHelped;
+        plan->frame_heavy_at = plan->frame_lone ? heavy_at(TS) : kHeavyAt;
+        plan->frame_quad_at = plan->frame_lone ? quad_at(TS) : kQuadAt;
+    }
 #if defined(CRENDER_FAULT) && CRENDER_FAULT == 2     // (round 5's defect back in, for the state check's own test: scripts/r6_faults.sh)
     if (plan->awaiting[par]) {
 #else
@@ -633,10 +646,10 @@ int run_bin_pass(crender_plan *plan, bool project, const float *d_tri, const flo
     if (T > 0 && direct) {
         // direct bins: one wavefront per 64 triangles
         HeavyReg hv;
-        if (L.hmax > 0 && plan->frame_lone && !(dbg & 2048)) {
+        if (plan->frame_hmax > 0) {
             hv.ctr = plan->hdr() + 2 + par; hv.flag = plan->hflag(); hv.slots = plan->hslots();
-            hv.hmax = (uint32_t)L.hmax;
-            hv.heavy_at = heavy_at(TS);
+            hv.hmax = (uint32_t)plan->frame_hmax;
+            hv.heavy_at = plan->frame_heavy_at;
         }
         if (L.ordered) {
             hv.grouped = plan->grouped(plan->hint_par);    // of the order this frame's raster pass reads

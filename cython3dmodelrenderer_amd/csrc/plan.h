@@ -81,6 +81,10 @@ struct crender_plan {
     const float *normal_z = nullptr;                        // crender_plan_set_normal_z
     bool frame_lone = true;       // the last bin pass belonged to a frame rendered for latency (no
                                   // CRENDER_OVERLAPPED_FRAMES): ordered dispatch and split heavy tiles
+    // how the last bin pass split long lists (run_bin_pass): helper triples in use (0: none), the list length that
+    // registers a tile, the length from which its parts are quadrants instead of halves
+    int frame_hmax = 0;
+    uint32_t frame_heavy_at = 0, frame_quad_at = 0;
     // Bin-list usage of every frame without a host round trip (crender_plan_poll_bin_usage): each
     // raster launch copies the header words crender_plan_last_bin_usage reads into a record of its
     // own in PINNED host memory the plan owns — two 16-byte stores by one thread of the launch,

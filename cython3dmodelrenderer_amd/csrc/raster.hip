@@ -428,7 +428,8 @@ struct TileLists {
     // heavy tiles (see register_heavy): null / 0 when the launch has no helper workgroups
     uint32_t *heavy_flag, *heavy_slots, *heavy_ctr_next;
     const uint32_t *heavy_ctr;  // how many tiles THIS frame's binning pass registered (it ran in an earlier launch)
-    int nhelp;                  // 3 * hmax helper workgroups
+    int nhelp;                  // 3 * (helper triples of this frame) helper workgroups
+    uint32_t quad_at;           // lists from here on are split in quadrants, shorter registered ones in halves
     // dispatch order (see build_order): null when the launch is not ordered
     int addr32;                  // framebuffer and attribute byte offsets fit 32 bits (see elem())
     const uint32_t *order, *hint, *hint_bad;
@@ -1727,7 +1728,7 @@ CR_DEV void raster_body(const float *__restrict__ proj, const float *__restrict_
     int rw = TS;                 // width of this workgroup's rectangle in the key plane's terms
     if (quad >= 0) {
         constexpr int HS = TS / 2;
-        if (end - beg >= quad_at(TS)) {         // four quadrants
+        if (end - beg >= L.quad_at) {           // four quadrants
             X0 += (quad & 1) * HS; Y0 += (quad >> 1) * HS;
             if (X1 > X0 + HS) X1 = X0 + HS;
             rw = HS;
@@ -2202,12 +2203,13 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     tl.T = (uint32_t)plan->last_T;
     tl.orig_of = plan->orig_of;
     tl.pos_of = plan->pos_of;
-    const bool split = direct && L.hmax > 0 && plan->frame_lone && !(dbg & 2048);
+    const bool split = direct && plan->frame_hmax > 0 && !(dbg & 2048);    // (lone frames: the plan's thresholds; frames in flight: long lists only)
     tl.heavy_flag = split ? plan->hflag() : nullptr;
     tl.heavy_slots = split ? plan->hslots() : nullptr;
     tl.heavy_ctr_next = plan->hdr() + 2 + (par ^ 1);
     tl.heavy_ctr = plan->hdr() + 2 + par;
-    tl.nhelp = split ? 3 * L.hmax : 0;
+    tl.nhelp = split ? 3 * plan->frame_hmax : 0;
+    tl.quad_at = plan->frame_quad_at;
     // ordered launches: read the order the previous launch left, leave one for the next
     const bool ordered = direct && L.ordered && plan->frame_lone && !(dbg & 1024);
     const int hp = plan->hint_par;
@@ -2245,7 +2247,7 @@ int run_raster_pass(crender_plan *plan, const float *proj, const float *d_col, c
     // (not on the split launches of small frames rendered alone: a device-scope atomic takes 1.5-2 us to come
     // back, and the one of the tile that ends such a launch ends it that much later — lone T-Rex 1024^2 16.8
     // against 15.2 us, profiles/r06/ab_stats_atomics.txt; on a frame of 130 us and more it is noise)
-    tl.stats = TS == 32 && !split ? plan->stats((int)(plan->ticket & 1u)) : nullptr;
+    tl.stats = TS == 32 && !(split && plan->frame_lone) ? plan->stats((int)(plan->ticket & 1u)) : nullptr;
     tl.stats_prev = TS == 32 ? plan->stats((int)((plan->ticket & 1u) ^ 1u)) : nullptr;
     tl.path = (uint32_t)path;
     const unsigned grid = (unsigned)(G.ntiles + tl.nhelp + (ordered ? 1 : 0));

@@ -68,9 +68,11 @@ enum {
      * splits tiles with long lists over several workgroups — all covered tiles then hold a
      * workgroup slot from the first microsecond to the last, which is the shortest a single frame
      * gets and leaves no room for a second frame's launch to overlap it.  With this flag the
-     * launch keeps plain raster order and one workgroup per tile (more frames per second, longer
-     * frame).  Pass the same value to crender_prepare and crender_draw.  Results do not depend on
-     * it. */
+     * launch keeps plain raster order and one workgroup per tile — but for its LONGEST lists (from 32
+     * records on in two halves, from 64 in four quadrants, at most 128 tiles), so that a frame that
+     * runs with few others, at the start and the end of a burst, does not end on them (more frames per
+     * second, longer frame).  Pass the same value to crender_prepare and crender_draw (the draw follows
+     * what the prepare decided).  Results do not depend on it. */
     CRENDER_OVERLAPPED_FRAMES = 4u,
     /* next row f1 fused: apply GuroIllumination.draw_illumination
      * (guro_illumination.py:20-27) to every pixel as it is stored — colour *= clip(n.l / (|n| +
